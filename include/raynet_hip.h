@@ -1,0 +1,226 @@
+/*
+ * raynet_hip.h -- C ABI of libraynet_hip.so: RayNet's forward_pass hot path on
+ * MI355X (gfx950).  This is the drop-in boundary.
+ *
+ * The reference has no C ABI: its operator interface is the set of PyCUDA
+ * closure factories in raynet/cuda_implementations/ (one .py per kernel family), each of which wraps one
+ * `prepared_call` of a __global__ kernel.  Every entry point below replaces one
+ * of those launches (kernel numbers K1..K12 as in SURVEY.md section 2.2); the
+ * comment above each function names the reference launcher (file:line) it
+ * stands in for.  INTEGRATION.md shows the ctypes stub a maintainer would put
+ * in place of each PyCUDA closure.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     the name ends in _host;
+ *   - the caller allocates every buffer and keeps it alive; the library never
+ *     allocates per call and never frees caller memory (reference: `to_gpu` in
+ *     the driver, raynet/forward_pass.py:515-538);
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as
+ *     void*; NULL = the null stream); no hidden global state, one rn_ctx per
+ *     device;
+ *   - return value: RN_OK or a negative rn_status; no exceptions cross the
+ *     boundary.  The Python mirror re-raises shape/dtype problems as
+ *     AssertionError like the reference (raynet_fp.py:291-301);
+ *   - msgs_in and msgs_out may alias (the reference always aliases them,
+ *     raynet_fp.py:321-323, mrf_cuda.py:73-75);
+ *   - there is NO CPU fallback in this library.  rn_create fails with
+ *     RN_ERR_NO_DEVICE when no gfx950 device is visible.
+ *
+ * Array layouts are the reference's:
+ *   features   [N][H+padding+1][W+padding+1][F] f32   (forward_pass.py:622-641)
+ *   P          [N][3][4] f32, P_inv [4][3] f32, camera_center [4] f32
+ *   voxel_grid [gx][gy][gz][3] f32                     (forward_pass.py:573-575)
+ *   ray_idxs   [n] i32, ray_idx = x*H + y              (sampling_schemes.cu:5-8)
+ *   rvi        [n][M][3] i32, rvc [n] i32
+ *   S (planes) [n][D] f32, S_voxel / msgs / S_new [n][M] f32
+ *   acc        [gx][gy][gz] f32 (log-odds)
+ */
+#ifndef RAYNET_HIP_H
+#define RAYNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RN_OK = 0,
+    RN_ERR_INVALID = -1,     /* bad argument / unsupported size          */
+    RN_ERR_HIP = -2,         /* a HIP runtime call failed                */
+    RN_ERR_NO_DEVICE = -3,   /* no usable gfx950 device                  */
+    RN_ERR_STATE = -4        /* call order (e.g. voxel grid not set)     */
+} rn_status;
+
+/* The values the reference bakes into its kernels as $literals
+ * (cuda_implementations/raynet_fp.py:230-248); here they are run-time. */
+typedef struct {
+    int32_t M;        /* generation_params.max_number_of_marched_voxels */
+    int32_t D;        /* depth_planes                                    */
+    int32_t N;        /* neighbors + 1                                   */
+    int32_t F;        /* feature channels                                */
+    int32_t H;        /* image height                                    */
+    int32_t W;        /* image width                                     */
+    int32_t padding;  /* generation_params.padding                       */
+    int32_t grid[3];  /* voxel grid shape                                */
+    float bbox[6];    /* scene.bbox: min xyz, max xyz                    */
+    int32_t device;   /* HIP device ordinal                              */
+} rn_config;
+
+typedef struct rn_ctx rn_ctx;
+
+/* perform_raynet_fp(M,D,N,F,H,W,padding,bbox,grid_shape,"sample_in_bbox")
+ * (raynet_fp.py:10-21): where the reference JIT-compiles, this validates the
+ * configuration and creates a context. */
+int rn_create(const rn_config *cfg, rn_ctx **out);
+void rn_destroy(rn_ctx *ctx);
+const char *rn_last_error(const rn_ctx *ctx);
+const char *rn_version(void);
+
+/* Voxel centres are read by K1/K2/K6/K11/K12 from the [gx][gy][gz][3] array
+ * (planes_voxels_mapping.cu:52-57).  The grid is separable, so the context keeps
+ * the three per-axis centre tables extracted from the caller's array (bit-equal
+ * values, 1.5 KB instead of 25 MB of gathers).  Call once per scene. */
+int rn_set_voxel_grid(rn_ctx *ctx, const float *voxel_grid, void *stream);
+
+/* GPUArray.fill (forward_pass.py:646-648, :678) */
+int rn_fill_f32(rn_ctx *ctx, float *dst, int64_t count, float value, void *stream);
+int rn_fill_i32(rn_ctx *ctx, int32_t *dst, int64_t count, int32_t value, void *stream);
+
+/* ---- stand-alone stages ------------------------------------------------ */
+
+/* sample_in_bbox for a list of rays -> ray_start/ray_end [n][3]
+ * (sampling_schemes.cu:44-90; what every fused kernel does first). */
+int rn_sample_rays(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *P_inv,
+                   const float *camera_center, float *ray_start, float *ray_end,
+                   void *stream);
+
+/* K8 batch_sample_points_in_bbox, launcher sample_points.py:12-54:
+ * points [n][D][4] */
+int rn_sample_points(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *P_inv,
+                     const float *camera_center, float *points, void *stream);
+
+/* K7 batch_compute_similarities (feature_similarities.cu:126-146): S [n][D] */
+int rn_compute_similarities(rn_ctx *ctx, int32_t n, const float *features, const float *P,
+                            const float *ray_start, const float *ray_end, float *S,
+                            void *stream);
+
+/* K5 batch_voxel_traversal, launcher ray_tracing_cuda.py:35-63 */
+int rn_voxel_traversal(rn_ctx *ctx, int32_t n, const float *ray_start, const float *ray_end,
+                       int32_t *rvi, int32_t *rvc, void *stream);
+
+/* K6 batch_planes_voxels_mapping, launcher planes_voxels_mapping_cuda.py:28-65 */
+int rn_planes_to_voxels(rn_ctx *ctx, int32_t n, const int32_t *rvi, const int32_t *rvc,
+                        const float *ray_start, const float *ray_end, const float *S,
+                        float *S_new, void *stream);
+
+/* K3 batch_belief_propagation, launcher mrf_cuda.py:37-79 */
+int rn_bp_sweep(rn_ctx *ctx, int32_t n, const float *S, const int32_t *rvi, const int32_t *rvc,
+                const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
+                void *stream);
+
+/* K4 batch_depth_estimation, launcher mrf_cuda.py:81-122 */
+int rn_depth_estimation(rn_ctx *ctx, int32_t n, const float *S, const int32_t *rvi,
+                        const int32_t *rvc, const float *acc, const float *msgs, float *S_new,
+                        void *stream);
+
+/* ---- fused kernels of the forward-pass drivers -------------------------- */
+
+/* K9 batch_multi_view_cnn_forward_pass, launcher similarities.py:101-130:
+ * sample + plane sweep -> S [n][D] */
+int rn_mvcnn_similarities(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                          const float *P, const float *P_inv, const float *camera_center,
+                          float *S, void *stream);
+
+/* K10 batch_multi_view_cnn_forward_pass_with_depth, launcher similarities.py:252-285:
+ * K9 + arg-max plane -> depth_map [n]; points [n][D][4] is filled too */
+int rn_mvcnn_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                   const float *P, const float *P_inv, const float *camera_center, float *S,
+                   float *points, float *depth_map, void *stream);
+
+/* K11 batch_mvcnn_planes_voxels_with_ray_marching, launcher
+ * mvcnn_with_ray_marching_and_voxels_mapping.py:137-174 */
+int rn_mvcnn_voxel_space(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                         const float *P, const float *P_inv, const float *camera_center,
+                         int32_t *rvi, int32_t *rvc, float *S_voxel, void *stream);
+
+/* K12 ..._with_depth, launcher mvcnn_with_ray_marching_and_voxels_mapping.py:339-378 */
+int rn_mvcnn_voxel_space_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
+                               const float *features, const float *P, const float *P_inv,
+                               const float *camera_center, int32_t *rvi, int32_t *rvc,
+                               float *S_voxel, float *depth_map, void *stream);
+
+/* K1 batch_raynet_fp, launcher raynet_fp.py:274-326 */
+int rn_fused_bp_sweep(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                      const float *P, const float *P_inv, const float *camera_center,
+                      int32_t *rvi, int32_t *rvc, float *S_voxel, const float *acc_in,
+                      const float *msgs_in, float *acc_out, float *msgs_out, void *stream);
+
+/* K2 batch_complete_depth_estimation, launcher raynet_fp.py:328-376 */
+int rn_fused_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                   const float *P, const float *P_inv, const float *camera_center,
+                   int32_t *rvi, int32_t *rvc, float *S_voxel, const float *acc,
+                   const float *msgs, float *depth_map, void *stream);
+
+/* ---- resident-scene path (what RayNetForwardPass runs on MI355X) -------- *
+ * The reference recomputes features, similarities, traversal and mapping in
+ * each of its 3 BP sweeps and again in the depth sweep (forward_pass.py:593-664,
+ * :682-736) and round-trips messages through host memory.  With 288 GB of HBM
+ * the per-ray state stays resident instead: rn_scene_prepare runs the
+ * K1-prefix once per reference image and keeps, per ray, the packed voxel list
+ * and the clipped+renormalised voxel-space column; the sweeps then stream it.
+ * Results are those of K1/K2 called with the same inputs.
+ *   vox  [n][M] i32  packed (x<<20 | y<<10 | z)
+ *   Sr   [n][M] f32  clip_and_renorm(S_voxel) (mrf_bp.cu:103-111)
+ * features_views: N device pointers (HOST array), one [Hf][Wf][F] map per view,
+ * so a bank of per-view feature maps needs no re-stacking per reference image. */
+int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
+                     const float *const *features_views_host, const float *P,
+                     const float *P_inv, const float *camera_center, int32_t *vox,
+                     int32_t *rvc, float *Sr, void *stream);
+
+/* acc_part: [rn_acc_copies()][gx][gy][gz] f32, zero before the first sweep of an
+ * iteration; messages are scattered into one copy per XCD. */
+int rn_acc_copies(const rn_ctx *ctx);
+int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
+                      const int32_t *rvc, const float *acc_in, float *msgs, float *acc_part,
+                      void *stream);
+/* acc_out = prior + sum over copies (+ optionally `extra`, e.g. nothing or a
+ * peer's partial); the copies are zeroed for the next iteration. */
+int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream);
+/* Only the local sum (no prior), written to acc_out; used before an all-reduce. */
+int rn_acc_reduce_local(rn_ctx *ctx, float *acc_part, float *acc_out, void *stream);
+int rn_acc_add_prior(rn_ctx *ctx, float *acc, float prior, void *stream);
+
+/* depth_map [n] and, when S_new != NULL, the per-ray distribution [n][M] */
+int rn_scene_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
+                   const int32_t *rvc, const float *acc, const float *msgs,
+                   const float *camera_center, float *S_new, float *depth_map, void *stream);
+
+/* ---- measurement -------------------------------------------------------- */
+/* Per-launch hipEvent timing on the stream each kernel runs on.  Between
+ * rn_prof_begin and rn_prof_end every kernel launch made through this context
+ * is bracketed by two events; rn_prof_end synchronises and returns, per launch,
+ * the kernel family (rn_kernel_id), its ray count and its duration. */
+typedef enum {
+    RN_K_TRAVERSE = 1,   /* voxel traversal (thread per ray)                 */
+    RN_K_SWEEP_MAP = 2,  /* plane sweep + softmax (+ planes->voxels mapping) */
+    RN_K_BP = 3,         /* BP sweep                                         */
+    RN_K_DEPTH = 4,      /* depth estimation / arg-max                       */
+    RN_K_ACC = 5,        /* accumulator combine / fill                       */
+    RN_K_OTHER = 6
+} rn_kernel_id;
+int rn_prof_begin(rn_ctx *ctx, int32_t capacity);
+int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *n_rays_host,
+                float *ms_host);
+
+/* hipEvent pair on `stream`; rn_timer_stop returns elapsed milliseconds after
+ * synchronising on the stop event (bench.py's per-kernel timing). */
+int rn_timer_start(rn_ctx *ctx, void *stream);
+int rn_timer_stop(rn_ctx *ctx, void *stream, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYNET_HIP_H */

@@ -1,0 +1,116 @@
+"""Loader of libraynet_hip.so (the C ABI declared in include/raynet_hip.h).
+
+The product path fails loudly when the HIP library is missing or no GPU is
+visible -- there is deliberately no CPU route in this package.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libraynet_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "raynet_hip.h")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17",
+    "-ffp-contract=off",        # index maps bit-exact w.r.t. the reference arithmetic
+    "-munsafe-fp-atomics",      # hardware global_atomic_add_f32 for the accumulator scatter
+    "-Wno-unused-value", "-fPIC", "-shared",
+]
+
+RN_OK = 0
+STATUS = {0: "RN_OK", -1: "RN_ERR_INVALID", -2: "RN_ERR_HIP", -3: "RN_ERR_NO_DEVICE",
+          -4: "RN_ERR_STATE"}
+
+
+class RaynetHipError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, "raynet_hip.hip"), os.path.join(CSRC, "raynet_kernels.h"), HEADER]
+    if not force and os.path.exists(LIB_PATH) and \
+            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + [srcs[0], "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+class Config(ctypes.Structure):
+    _fields_ = [
+        ("M", ctypes.c_int32), ("D", ctypes.c_int32), ("N", ctypes.c_int32),
+        ("F", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("padding", ctypes.c_int32), ("grid", ctypes.c_int32 * 3),
+        ("bbox", ctypes.c_float * 6), ("device", ctypes.c_int32),
+    ]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int32
+_L = ctypes.c_int64
+_F = ctypes.c_float
+
+# name -> argtypes; mirrors include/raynet_hip.h one to one (checked by
+# tests/test_abi.py against the header text)
+SIGNATURES = {
+    "rn_create": [ctypes.POINTER(Config), ctypes.POINTER(_P)],
+    "rn_destroy": [_P],
+    "rn_last_error": [_P],
+    "rn_version": [],
+    "rn_set_voxel_grid": [_P, _P, _P],
+    "rn_fill_f32": [_P, _P, _L, _F, _P],
+    "rn_fill_i32": [_P, _P, _L, _I, _P],
+    "rn_sample_rays": [_P, _I, _P, _P, _P, _P, _P, _P],
+    "rn_sample_points": [_P, _I, _P, _P, _P, _P, _P],
+    "rn_compute_similarities": [_P, _I, _P, _P, _P, _P, _P, _P],
+    "rn_voxel_traversal": [_P, _I, _P, _P, _P, _P, _P],
+    "rn_planes_to_voxels": [_P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "rn_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_depth_estimation": [_P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "rn_mvcnn_similarities": [_P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "rn_mvcnn_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_mvcnn_voxel_space": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_mvcnn_voxel_space_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_fused_bp_sweep": [_P, _I] + [_P] * 13,
+    "rn_fused_depth": [_P, _I] + [_P] * 12,
+    "rn_scene_prepare": [_P, _I, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P],
+    "rn_acc_copies": [_P],
+    "rn_scene_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "rn_acc_combine": [_P, _P, _F, _P, _P],
+    "rn_acc_reduce_local": [_P, _P, _P, _P],
+    "rn_acc_add_prior": [_P, _P, _F, _P],
+    "rn_scene_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_prof_begin": [_P, _I],
+    "rn_prof_end": [_P, ctypes.POINTER(_I), _P, _P, _P],
+    "rn_timer_start": [_P, _P],
+    "rn_timer_stop": [_P, _P, ctypes.POINTER(_F)],
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library; raises RaynetHipError if it was never built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RaynetHipError(
+            "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(raynet_amd has no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.rn_destroy.restype = None
+    lib.rn_last_error.restype = ctypes.c_char_p
+    lib.rn_version.restype = ctypes.c_char_p
+    _lib = lib
+    return lib

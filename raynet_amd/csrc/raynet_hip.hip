@@ -1,0 +1,1092 @@
+// raynet_hip.hip -- __global__ kernels and the C ABI (include/raynet_hip.h) of the
+// RayNet forward_pass hot path for MI355X / gfx950.  No CPU fallback lives here.
+#include "raynet_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/raynet_hip.h"
+
+using namespace rn;
+
+namespace {
+
+constexpr int BLOCK = 256;               // 4 wavefronts = 4 rays per workgroup
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+constexpr int NXCD = 8;
+
+// XCD-aware remap: the dispatcher is observed to place block b on XCD b % 8; give
+// every XCD one contiguous slice of the ray list so its private L2 sees
+// neighbouring rays (speed only -- any placement is correct).
+__device__ __forceinline__ int xcd_block(int b, int nblocks) {
+    const int q = nblocks / NXCD, r = nblocks % NXCD;
+    const int xcd = b % NXCD, pos = b / NXCD;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + pos;
+}
+
+__device__ __forceinline__ int ray_of_wave(int n, int &lane) {
+    lane = threadIdx.x & (WAVE - 1);
+    const int b = xcd_block(blockIdx.x, gridDim.x);
+    const int r = b * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    return r < n ? uniform(r) : -1;
+}
+
+// ------------------------------------------------------------- small kernels
+__global__ void k_fill_f32(float *dst, int64_t n, float v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = v;
+}
+__global__ void k_fill_i32(int32_t *dst, int64_t n, int32_t v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = v;
+}
+// per-axis centre tables out of the [gx][gy][gz][3] array
+__global__ void k_extract_axes(const float *grid, int gx, int gy, int gz, float *axes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < gx)
+        axes[i] = grid[((size_t)i * gy * gz) * 3 + 0];
+    else if (i < gx + gy)
+        axes[i] = grid[((size_t)(i - gx) * gz) * 3 + 1];
+    else if (i < gx + gy + gz)
+        axes[i] = grid[((size_t)(i - gx - gy)) * 3 + 2];
+}
+__global__ void k_acc_combine(float *part, int copies, int64_t G, float prior, float *out,
+                              int add_prior) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < G;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int c = 0; c < copies; c++) {
+            s += part[c * G + i];
+            part[c * G + i] = 0.0f;
+        }
+        out[i] = add_prior ? prior + s : s;
+    }
+}
+__global__ void k_add_scalar(float *a, int64_t n, float v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        a[i] = v + a[i];
+}
+
+// ------------------------------------------------------------ K8 / sampling
+__global__ void k_sample_rays(Params p, int n, const int32_t *__restrict__ ray_idxs,
+                              const float *__restrict__ P_inv, const float *__restrict__ cc,
+                              float *starts, float *ends) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float s[3], e[3];
+    sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+    for (int i = 0; i < 3; i++) {
+        starts[3 * r + i] = s[i];
+        ends[3 * r + i] = e[i];
+    }
+}
+// sampling_schemes.cu:92-122: one wave per ray, lanes over planes
+__global__ void k_sample_points(Params p, int n, const int32_t *__restrict__ ray_idxs,
+                                const float *__restrict__ P_inv, const float *__restrict__ cc,
+                                float *points) {
+    int lane;
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    float s[3], e[3];
+    sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+    float4 *row = reinterpret_cast<float4 *>(points) + (size_t)r * p.D;
+    for (int k = lane; k < p.D; k += WAVE) {
+        float pt[3];
+        plane_point(s, e, k, p.D, pt);
+        row[k] = make_float4(pt[0], pt[1], pt[2], 1.0f);
+    }
+}
+
+// ------------------------------------------------------------ K5 traversal
+// One thread per ray.  Source of the segment: explicit starts/ends, or the
+// camera (sample_in_bbox), as in the fused kernels.
+template <bool PACKED>
+__global__ void k_traverse(Params p, int n, const int32_t *__restrict__ ray_idxs,
+                           const float *__restrict__ P_inv, const float *__restrict__ cc,
+                           const float *__restrict__ starts, const float *__restrict__ ends,
+                           int32_t *vox, int32_t *rvc) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float s[3], e[3];
+    if (ray_idxs) {
+        sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+    } else {
+        for (int i = 0; i < 3; i++) {
+            s[i] = starts[3 * r + i];
+            e[i] = ends[3 * r + i];
+        }
+    }
+    int count;
+    if (PACKED) {
+        int32_t *row = vox + (size_t)r * p.M;
+        count = dda(p, s, e, [&](int i, int x, int y, int z) { row[i] = pack_voxel(x, y, z); });
+    } else {
+        int32_t *row = vox + (size_t)r * p.M * 3;
+        count = dda(p, s, e, [&](int i, int x, int y, int z) {
+            row[3 * i] = x;
+            row[3 * i + 1] = y;
+            row[3 * i + 2] = z;
+        });
+    }
+    rvc[r] = count;   // written even when 0
+}
+
+// ---------------------------------------- plane sweep (+ mapping) per wavefront
+// SIM      0: read the plane column from S_in [n][D] (K6)
+//          1: generic sweep (any N, F), 2: cooperative sweep (F = 4*LPS, N = NV)
+// MAPMODE  0: write the plane column to S_planes [n][D]            (K7 / K9 / K10)
+//          1: map to voxels, write S_voxel = vals / sum             (K6 / K11 / K1 / K2 prefix)
+//          2: as 1, then clip_and_renorm (mrf_bp.cu:103-111) -> Sr  (resident-scene path)
+// Dynamic LDS: [axes gx+gy+gz][per wave: D plane column][per wave: M values]
+template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
+__global__ __launch_bounds__(BLOCK) void k_sweep_map(
+    Params p, int n, const int32_t *__restrict__ ray_idxs, FeatureViews fv,
+    const float *__restrict__ P, const float *__restrict__ P_inv, const float *__restrict__ cc,
+    const float *__restrict__ starts, const float *__restrict__ ends,
+    const float *__restrict__ S_in, const float *__restrict__ axes_g,
+    const int32_t *__restrict__ vox, const int32_t *__restrict__ rvc, float *S_planes,
+    float *S_voxel, float *depth_from_planes, float *points) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int naxes = p.gx + p.gy + p.gz;
+    float *axes = smem;
+    const int wid = threadIdx.x >> 6;
+    float *Sl = smem + ((naxes + 3) & ~3) + wid * (p.D + p.M);
+    float *vals = Sl + p.D;
+    if (MAPMODE != 0) {
+        for (int i = threadIdx.x; i < naxes; i += BLOCK) axes[i] = axes_g[i];
+        __syncthreads();
+    }
+    int lane;
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+
+    float s[3], e[3];
+    if (ray_idxs) {
+        sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            s[i] = starts[3 * r + i];
+            e[i] = ends[3 * r + i];
+        }
+    }
+
+    if (SIM == 0) {
+        for (int k = lane; k < p.D; k += WAVE) Sl[k] = S_in[(size_t)r * p.D + k];
+    } else {
+        if (SIM == 1)
+            sweep_generic(p, fv, P, s, e, lane, Sl);
+        else
+            sweep_coop<NV, LPS>(p, fv, P, s, e, lane, Sl);
+        wave_sync();
+        softmax_column(p.D, lane, Sl);
+    }
+    wave_sync();
+
+    if (MAPMODE == 0) {
+        for (int k = lane; k < p.D; k += WAVE) S_planes[(size_t)r * p.D + k] = Sl[k];
+        if (depth_from_planes) {
+            // similarities.py:199-227: points, first arg-max plane, distance to the camera
+            float best = -INFINITY;
+            int best_k = 0;
+            for (int k = lane; k < p.D; k += WAVE) {
+                float pt[3];
+                plane_point(s, e, k, p.D, pt);
+                reinterpret_cast<float4 *>(points)[(size_t)r * p.D + k] =
+                    make_float4(pt[0], pt[1], pt[2], 1.0f);
+                if (Sl[k] > best) {
+                    best = Sl[k];
+                    best_k = k;
+                }
+            }
+            // first maximum: larger value wins, then smaller index
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o);
+                const int ok = __shfl_xor(best_k, o);
+                if (ob > best || (ob == best && ok < best_k)) {
+                    best = ob;
+                    best_k = ok;
+                }
+            }
+            if (lane == 0) {
+                float pt[3];
+                plane_point(s, e, best_k, p.D, pt);
+                float sum = 0.0f;
+                for (int i = 0; i < 3; i++) {
+                    const float d = pt[i] - cc[i];
+                    sum += d * d;
+                }
+                depth_from_planes[r] = sqrtf(sum);
+            }
+        }
+        return;
+    }
+
+    const int count = min(uniform(rvc[r]), p.M);
+    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+    float *out = S_voxel + (size_t)r * p.M;
+    const float srsum = map_planes_to_voxels<PACKED>(p, axes, vrow, count, s, e, Sl, vals, lane);
+    if (MAPMODE == 1) {
+        for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
+    } else {
+        float sum = 0.0f;
+        for (int i = lane; i < count; i += WAVE) {
+            const float v = clampf(vals[i] / srsum, (float)1e-5, (float)(1 - 1e-5));
+            vals[i] = v;
+            sum += v;
+        }
+        sum = wave_sum(sum);
+        for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / sum;
+    }
+}
+
+// ------------------------------------------------------------- K3: BP sweep
+// One wavefront per ray, NCH chunks of 64 voxels held in registers.
+//   CLIP_IN: S is the raw voxel-space column (API mode) and is clipped +
+//            renormalised here; otherwise it is the resident Sr.
+//   acc_out may be one of several per-XCD copies (xcd_stride != 0).
+template <int NCH, bool PACKED, bool CLIP_IN, bool XCD_LOCAL>
+__global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
+                                              const int32_t *__restrict__ vox,
+                                              const int32_t *__restrict__ rvc,
+                                              const float *__restrict__ acc_in,
+                                              const float *msgs_in, float *acc_out,
+                                              float *msgs_out, int64_t xcd_stride) {
+    int lane;
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    const int count = min(uniform(rvc[r]), p.M);
+    if (count <= 1) return;   // mrf_np.py:300
+    const float *Srow = S + (size_t)r * p.M;
+    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+    const float *min_row = msgs_in + (size_t)r * p.M;
+    float *mout_row = msgs_out + (size_t)r * p.M;
+    if (xcd_stride) {
+        // the XCD this workgroup really runs on; copies are private per XCD
+        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
+        acc_out += xcc * xcd_stride;
+    }
+
+    float sv[NCH], ov[NCH], tsv[NCH], cex[NCH], wv[NCH];
+    int lin[NCH];
+    float ssum = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        const int i = ch * WAVE + lane;
+        sv[ch] = 0.0f;
+        if (ch * WAVE < count && i < count) {
+            float v = Srow[i];
+            if (CLIP_IN) v = clampf(v, (float)1e-5, (float)(1 - 1e-5));
+            sv[ch] = v;
+            ssum += v;
+        }
+    }
+    if (CLIP_IN) {
+        ssum = wave_sum(ssum);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) sv[ch] = sv[ch] / ssum;
+    }
+
+    // pass A: occupancy, exclusive cumprod T, w = o*T*s, exclusive cumsum C
+    float carryT = 1.0f, carryC = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        if (ch * WAVE < count) {
+            const int i = ch * WAVE + lane;
+            const bool valid = i < count;
+            float o = 0.0f;
+            lin[ch] = 0;
+            if (valid) {
+                int x, y, z;
+                load_voxel<PACKED>(vrow, i, x, y, z);
+                lin[ch] = (x * p.gy + y) * p.gz + z;
+                o = occupancy_to_ray(acc_in[lin[ch]], min_row[i]);
+            }
+            const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
+            const float T = carryT * wave_shift1(incl, 1.0f);
+            carryT = carryT * lane63(incl);
+            const float ts = T * sv[ch];
+            const float w = valid ? o * ts : 0.0f;
+            const float inclC = wave_scan_add(w);
+            cex[ch] = carryC + wave_shift1(inclC, 0.0f);
+            carryC = carryC + lane63(inclC);
+            ov[ch] = o;
+            tsv[ch] = ts;
+            wv[ch] = w;
+        }
+    }
+    const float W = carryC;   // cumsum1 of mrf_bp.cu:115-133
+
+    // pass B: messages (mrf_bp.cu:136-167) and scatter (:170-176)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        if (ch * WAVE < count) {
+            const int i = ch * WAVE + lane;
+            if (i < count) {
+                const float cin = cex[ch] + wv[ch];
+                float pos = cex[ch] + tsv[ch];
+                const float neg = cex[ch] + (W - cin) / (1.0f - ov[ch]);
+                pos = pos / (pos + neg);
+                const float m = logf(pos) - logf(1.0f - pos);
+                mout_row[i] = m;
+                if (XCD_LOCAL)   // copy private to this XCD: its own L2 is the coherence point
+                    __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------- K4 / K2 tail: depth estimate
+// Writes the distribution (if S_new) and/or the arg-max depth (if depth_map).
+template <int NCH, bool PACKED, bool CLIP_IN>
+__global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S,
+                                                 const int32_t *__restrict__ vox,
+                                                 const int32_t *__restrict__ rvc,
+                                                 const float *__restrict__ acc,
+                                                 const float *__restrict__ msgs,
+                                                 const float *__restrict__ axes,
+                                                 const float *__restrict__ cc, float *S_new,
+                                                 float *depth_map) {
+    int lane;
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    const int count = min(uniform(rvc[r]), p.M);
+    const float *Srow = S + (size_t)r * p.M;
+    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+    const float *mrow = msgs + (size_t)r * p.M;
+
+    float best = -INFINITY;
+    int best_i = 0;
+    if (count > 1) {
+        float sv[NCH], wv[NCH];
+        float ssum = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const int i = ch * WAVE + lane;
+            sv[ch] = 0.0f;
+            if (ch * WAVE < count && i < count) {
+                float v = Srow[i];
+                if (CLIP_IN) v = clampf(v, (float)1e-5, (float)(1 - 1e-5));
+                sv[ch] = v;
+                ssum += v;
+            }
+        }
+        if (CLIP_IN) {
+            ssum = wave_sum(ssum);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) sv[ch] = sv[ch] / ssum;
+        }
+        float carryT = 1.0f, wsum = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            wv[ch] = 0.0f;
+            if (ch * WAVE < count) {
+                const int i = ch * WAVE + lane;
+                const bool valid = i < count;
+                float o = 0.0f;
+                if (valid) {
+                    int x, y, z;
+                    load_voxel<PACKED>(vrow, i, x, y, z);
+                    o = occupancy_to_ray(acc[(x * p.gy + y) * p.gz + z], mrow[i]);
+                }
+                const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
+                const float T = carryT * wave_shift1(incl, 1.0f);
+                carryT = carryT * lane63(incl);
+                wv[ch] = valid ? o * T * sv[ch] : 0.0f;
+                wsum += wv[ch];
+            }
+        }
+        wsum = wave_sum(wsum);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const int i = ch * WAVE + lane;
+            if (ch * WAVE < count && i < count) {
+                const float d = wv[ch] / wsum;
+                if (S_new) S_new[(size_t)r * p.M + i] = d;
+                if (d > best) {   // ascending i per lane: keeps the first maximum
+                    best = d;
+                    best_i = i;
+                }
+            }
+        }
+    } else if (S_new) {
+        // mrf_np.py:370-377: skipped rays keep an all-zero row (first `count` entries)
+        for (int i = lane; i < count; i += WAVE) S_new[(size_t)r * p.M + i] = 0.0f;
+    }
+    if (!depth_map) return;
+    // raynet_fp.py:193-226.  Entries beyond count are zero in the reference's
+    // zero-filled buffer and every d_i > 0, so the arg-max lies in [0, count);
+    // for count <= 1 the row is all zeros and index 0 wins.
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(best_i, o);
+        if (ob > best || (ob == best && oi < best_i)) {
+            best = ob;
+            best_i = oi;
+        }
+    }
+    if (lane == 0) {
+        int x = 0, y = 0, z = 0;
+        if (count > 0) load_voxel<PACKED>(vrow, count > 1 ? best_i : 0, x, y, z);
+        const float pt[3] = {axes[x], axes[p.gx + y], axes[p.gx + p.gy + z]};
+        float sum = 0.0f;
+        for (int i = 0; i < 3; i++) {
+            const float d = pt[i] - cc[i];
+            sum += d * d;
+        }
+        depth_map[r] = sqrtf(sum);
+    }
+}
+
+// K12 tail: arg-max of the mapped (not BP-refined) voxel column -> depth
+template <bool PACKED>
+__global__ __launch_bounds__(BLOCK) void k_argmax_depth(Params p, int n, const float *S_voxel,
+                                                        const int32_t *__restrict__ vox,
+                                                        const int32_t *__restrict__ rvc,
+                                                        const float *__restrict__ axes,
+                                                        const float *__restrict__ cc,
+                                                        float *depth_map) {
+    int lane;
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    const int count = min(uniform(rvc[r]), p.M);
+    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+    float best = -INFINITY;
+    int best_i = 0;
+    for (int i = lane; i < count; i += WAVE) {
+        const float v = S_voxel[(size_t)r * p.M + i];
+        if (v > best) {
+            best = v;
+            best_i = i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(best_i, o);
+        if (ob > best || (ob == best && oi < best_i)) {
+            best = ob;
+            best_i = oi;
+        }
+    }
+    if (lane == 0) {
+        // a zero-filled tail (value 0) beats only a non-positive head; mapped
+        // values are positive, so the winner is inside [0, count) when count > 0
+        int x = 0, y = 0, z = 0;
+        if (count > 0 && best > 0.0f) load_voxel<PACKED>(vrow, best_i, x, y, z);
+        else if (count > 0) load_voxel<PACKED>(vrow, 0, x, y, z);
+        const float pt[3] = {axes[x], axes[p.gx + y], axes[p.gx + p.gy + z]};
+        float sum = 0.0f;
+        for (int i = 0; i < 3; i++) {
+            const float d = pt[i] - cc[i];
+            sum += d * d;
+        }
+        depth_map[r] = sqrtf(sum);
+    }
+}
+
+}  // namespace
+
+// =============================================================== host side
+struct rn_ctx {
+    rn_config cfg;
+    Params p;
+    float *axes;          // device, gx+gy+gz
+    bool have_axes;
+    int copies;           // accumulator copies used by the resident path
+    int acc_mode;         // 0: one copy, agent-scope atomics; 1: one copy per XCD, agent scope;
+                          // 2: one copy per XCD, atomics resolved in that XCD's L2
+    hipEvent_t ev0, ev1;
+    // per-launch profiling (rn_prof_begin / rn_prof_end)
+    bool prof_on;
+    int prof_cap, prof_n;
+    hipEvent_t *prof_ev;      // 2 * prof_cap
+    int32_t *prof_id, *prof_rays;
+    char err[512];
+};
+
+// Brackets one kernel launch with two events on its stream when profiling is on.
+struct ProfScope {
+    rn_ctx *c;
+    hipStream_t st;
+    int slot;
+    ProfScope(rn_ctx *ctx, int id, int n_rays, hipStream_t s) : c(ctx), st(s), slot(-1) {
+        if (c->prof_on && c->prof_n < c->prof_cap) {
+            slot = c->prof_n++;
+            c->prof_id[slot] = id;
+            c->prof_rays[slot] = n_rays;
+            (void)hipEventRecord(c->prof_ev[2 * slot], st);
+        }
+    }
+    ~ProfScope() {
+        if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], st);
+    }
+};
+
+namespace {
+
+int fail(rn_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define RN_HIP(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(ctx, RN_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define RN_LAUNCH_CHECK(ctx)                                                           \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess)                                                          \
+            return fail(ctx, RN_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline int ray_blocks(int n) { return (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; }
+inline int thread_blocks(int n) { return (n + BLOCK - 1) / BLOCK; }
+inline int fill_blocks(int64_t n) {
+    int64_t b = (n + BLOCK - 1) / BLOCK;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+inline size_t sweep_lds(const Params &p) {
+    return sizeof(float) * ((size_t)((p.gx + p.gy + p.gz + 3) & ~3) +
+                            (size_t)WAVES_PER_BLOCK * (p.D + p.M));
+}
+
+FeatureViews stacked_views(const Params &p, const float *features) {
+    FeatureViews fv;
+    const size_t dim = (size_t)p.Hf * p.Wf * p.F;
+    for (int v = 0; v < MAX_VIEWS; v++) fv.v[v] = v < p.N ? features + dim * v : nullptr;
+    return fv;
+}
+
+struct SweepArgs {
+    int n;
+    const int32_t *ray_idxs;
+    FeatureViews fv;
+    const float *P, *P_inv, *cc, *starts, *ends, *S_in;
+    const int32_t *vox, *rvc;
+    float *S_planes, *S_voxel, *depth_from_planes, *points;
+};
+
+template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
+void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
+    ProfScope prof(ctx, RN_K_SWEEP_MAP, a.n, st);
+    hipLaunchKernelGGL((k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>), dim3(ray_blocks(a.n)),
+                       dim3(BLOCK), sweep_lds(ctx->p), st, ctx->p, a.n, a.ray_idxs, a.fv, a.P,
+                       a.P_inv, a.cc, a.starts, a.ends, a.S_in, ctx->axes, a.vox, a.rvc,
+                       a.S_planes, a.S_voxel, a.depth_from_planes, a.points);
+}
+
+// pick the plane-sweep flavour: cooperative for F=32 and 2..9 views, generic otherwise
+template <int MAPMODE, bool PACKED>
+void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream_t st) {
+    const Params &p = ctx->p;
+    if (!have_features) {
+        launch_sweep_t<0, 1, 8, MAPMODE, PACKED>(ctx, a, st);
+        return;
+    }
+    if (p.F == 32 && getenv("RAYNET_HIP_GENERIC_SWEEP") == nullptr) {
+        switch (p.N) {
+#define RN_CASE(NV_)                                                  \
+    case NV_:                                                         \
+        launch_sweep_t<2, NV_, 8, MAPMODE, PACKED>(ctx, a, st);       \
+        return;
+            RN_CASE(2) RN_CASE(3) RN_CASE(4) RN_CASE(5) RN_CASE(6) RN_CASE(7) RN_CASE(8) RN_CASE(9)
+#undef RN_CASE
+            default: break;
+        }
+    }
+    launch_sweep_t<1, 1, 8, MAPMODE, PACKED>(ctx, a, st);
+}
+
+template <bool PACKED, bool CLIP_IN, bool XCD_LOCAL>
+int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
+              const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
+              int64_t xcd_stride, hipStream_t st) {
+    const int nch = (ctx->p.M + WAVE - 1) / WAVE;
+    ProfScope prof(ctx, RN_K_BP, n, st);
+#define RN_BP(NCH_)                                                                       \
+    hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, XCD_LOCAL>), dim3(ray_blocks(n)),     \
+                       dim3(BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, acc_out, \
+                       msgs_out, xcd_stride)
+    if (nch <= 2) RN_BP(2);
+    else if (nch <= 4) RN_BP(4);
+    else if (nch <= 6) RN_BP(6);
+    else if (nch <= 8) RN_BP(8);
+    else if (nch <= 12) RN_BP(12);
+    else RN_BP(16);
+#undef RN_BP
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+template <bool PACKED, bool CLIP_IN>
+int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
+                 const float *acc, const float *msgs, const float *cc, float *S_new,
+                 float *depth_map, hipStream_t st) {
+    const int nch = (ctx->p.M + WAVE - 1) / WAVE;
+    ProfScope prof(ctx, RN_K_DEPTH, n, st);
+#define RN_DE(NCH_)                                                                             \
+    hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
+                       ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, S_new, depth_map)
+    if (nch <= 2) RN_DE(2);
+    else if (nch <= 4) RN_DE(4);
+    else if (nch <= 6) RN_DE(6);
+    else if (nch <= 8) RN_DE(8);
+    else if (nch <= 12) RN_DE(12);
+    else RN_DE(16);
+#undef RN_DE
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int need_axes(rn_ctx *ctx) {
+    if (!ctx->have_axes)
+        return fail(ctx, RN_ERR_STATE, "rn_set_voxel_grid must be called before this entry point");
+    return RN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rn_version(void) { return "raynet_hip 0.1 (gfx950)"; }
+
+const char *rn_last_error(const rn_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int rn_create(const rn_config *cfg, rn_ctx **out) {
+    if (!cfg || !out) return RN_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RN_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return RN_ERR_NO_DEVICE;
+    if (cfg->M < 1 || cfg->M > 1024 || cfg->D < 2 || cfg->D > 4096 || cfg->N < 2 ||
+        cfg->N > MAX_VIEWS || cfg->F < 1 || cfg->H < 1 || cfg->W < 1 || cfg->padding < 0)
+        return RN_ERR_INVALID;
+    for (int i = 0; i < 3; i++)
+        if (cfg->grid[i] < 1 || cfg->grid[i] > 1024 || !(cfg->bbox[3 + i] > cfg->bbox[i]))
+            return RN_ERR_INVALID;
+    if (hipSetDevice(cfg->device) != hipSuccess) return RN_ERR_HIP;
+    rn_ctx *ctx = new rn_ctx();
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->cfg = *cfg;
+    Params &p = ctx->p;
+    p.M = cfg->M; p.D = cfg->D; p.N = cfg->N; p.F = cfg->F;
+    p.H = cfg->H; p.W = cfg->W; p.padding = cfg->padding;
+    p.gx = cfg->grid[0]; p.gy = cfg->grid[1]; p.gz = cfg->grid[2];
+    p.Hf = cfg->H + cfg->padding + 1;
+    p.Wf = cfg->W + cfg->padding + 1;
+    for (int i = 0; i < 6; i++) p.bbox[i] = cfg->bbox[i];
+    // RAYNET_HIP_ACC_MODE picks how rn_scene_bp_sweep scatters (see rn_ctx::acc_mode)
+    const char *am = getenv("RAYNET_HIP_ACC_MODE");
+    ctx->acc_mode = am ? atoi(am) : 0;
+    if (ctx->acc_mode < 0 || ctx->acc_mode > 2) ctx->acc_mode = 0;
+    ctx->copies = ctx->acc_mode == 0 ? 1 : NXCD;
+    if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return RN_ERR_HIP;
+    }
+    if (sweep_lds(p) > 160 * 1024) {
+        hipFree(ctx->axes);
+        delete ctx;
+        return RN_ERR_INVALID;
+    }
+    *out = ctx;
+    return RN_OK;
+}
+
+void rn_destroy(rn_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->cfg.device);
+    if (ctx->axes) hipFree(ctx->axes);
+    hipEventDestroy(ctx->ev0);
+    hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < 2 * ctx->prof_cap; i++) hipEventDestroy(ctx->prof_ev[i]);
+    delete[] ctx->prof_ev;
+    delete[] ctx->prof_id;
+    delete[] ctx->prof_rays;
+    delete ctx;
+}
+
+int rn_set_voxel_grid(rn_ctx *ctx, const float *voxel_grid, void *stream) {
+    if (!ctx || !voxel_grid) return fail(ctx, RN_ERR_INVALID, "null argument");
+    const Params &p = ctx->p;
+    const int tot = p.gx + p.gy + p.gz;
+    hipLaunchKernelGGL(k_extract_axes, dim3(thread_blocks(tot)), dim3(BLOCK), 0, S(stream),
+                       voxel_grid, p.gx, p.gy, p.gz, ctx->axes);
+    RN_LAUNCH_CHECK(ctx);
+    ctx->have_axes = true;
+    return RN_OK;
+}
+
+int rn_fill_f32(rn_ctx *ctx, float *dst, int64_t count, float value, void *stream) {
+    if (!ctx || (!dst && count)) return fail(ctx, RN_ERR_INVALID, "null argument");
+    if (count <= 0) return RN_OK;
+    hipLaunchKernelGGL(k_fill_f32, dim3(fill_blocks(count)), dim3(BLOCK), 0, S(stream), dst, count,
+                       value);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_fill_i32(rn_ctx *ctx, int32_t *dst, int64_t count, int32_t value, void *stream) {
+    if (!ctx || (!dst && count)) return fail(ctx, RN_ERR_INVALID, "null argument");
+    if (count <= 0) return RN_OK;
+    hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks(count)), dim3(BLOCK), 0, S(stream), dst, count,
+                       value);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_sample_rays(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *P_inv,
+                   const float *camera_center, float *ray_start, float *ray_end, void *stream) {
+    if (!ctx || n < 0 || !ray_idxs || !P_inv || !camera_center || !ray_start || !ray_end)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    hipLaunchKernelGGL(k_sample_rays, dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream), ctx->p, n,
+                       ray_idxs, P_inv, camera_center, ray_start, ray_end);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_sample_points(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *P_inv,
+                     const float *camera_center, float *points, void *stream) {
+    if (!ctx || n < 0 || !ray_idxs || !P_inv || !camera_center || !points)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    hipLaunchKernelGGL(k_sample_points, dim3(ray_blocks(n)), dim3(BLOCK), 0, S(stream), ctx->p, n,
+                       ray_idxs, P_inv, camera_center, points);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_compute_similarities(rn_ctx *ctx, int32_t n, const float *features, const float *P,
+                            const float *ray_start, const float *ray_end, float *Sp,
+                            void *stream) {
+    if (!ctx || n < 0 || !features || !P || !ray_start || !ray_end || !Sp)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    SweepArgs a{n, nullptr, stacked_views(ctx->p, features), P, nullptr, nullptr, ray_start,
+                ray_end, nullptr, nullptr, nullptr, Sp, nullptr, nullptr, nullptr};
+    launch_sweep<0, false>(ctx, a, true, S(stream));
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_voxel_traversal(rn_ctx *ctx, int32_t n, const float *ray_start, const float *ray_end,
+                       int32_t *rvi, int32_t *rvc, void *stream) {
+    if (!ctx || n < 0 || !ray_start || !ray_end || !rvi || !rvc)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    {
+        ProfScope prof(ctx, RN_K_TRAVERSE, n, S(stream));
+        hipLaunchKernelGGL((k_traverse<false>), dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream),
+                           ctx->p, n, (const int32_t *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, ray_start, ray_end, rvi, rvc);
+    }
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_planes_to_voxels(rn_ctx *ctx, int32_t n, const int32_t *rvi, const int32_t *rvc,
+                        const float *ray_start, const float *ray_end, const float *Sp,
+                        float *S_new, void *stream) {
+    if (!ctx || n < 0 || !rvi || !rvc || !ray_start || !ray_end || !Sp || !S_new)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    int rc = need_axes(ctx);
+    if (rc) return rc;
+    if (n == 0) return RN_OK;
+    SweepArgs a{n, nullptr, FeatureViews{}, nullptr, nullptr, nullptr, ray_start, ray_end, Sp,
+                rvi, rvc, nullptr, S_new, nullptr, nullptr};
+    launch_sweep<1, false>(ctx, a, false, S(stream));
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sv, const int32_t *rvi, const int32_t *rvc,
+                const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
+                void *stream) {
+    if (!ctx || n < 0 || !Sv || !rvi || !rvc || !acc_in || !msgs_in || !acc_out || !msgs_out)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    return launch_bp<false, true, false>(ctx, n, Sv, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
+                                  S(stream));
+}
+
+int rn_depth_estimation(rn_ctx *ctx, int32_t n, const float *Sv, const int32_t *rvi,
+                        const int32_t *rvc, const float *acc, const float *msgs, float *S_new,
+                        void *stream) {
+    if (!ctx || n < 0 || !Sv || !rvi || !rvc || !acc || !msgs || !S_new)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    return launch_depth<false, true>(ctx, n, Sv, rvi, rvc, acc, msgs, nullptr, S_new, nullptr,
+                                     S(stream));
+}
+
+int rn_mvcnn_similarities(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                          const float *P, const float *P_inv, const float *camera_center,
+                          float *Sp, void *stream) {
+    if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !Sp)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    SweepArgs a{n, ray_idxs, stacked_views(ctx->p, features), P, P_inv, camera_center, nullptr,
+                nullptr, nullptr, nullptr, nullptr, Sp, nullptr, nullptr, nullptr};
+    launch_sweep<0, false>(ctx, a, true, S(stream));
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_mvcnn_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                   const float *P, const float *P_inv, const float *camera_center, float *Sp,
+                   float *points, float *depth_map, void *stream) {
+    if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !Sp ||
+        !points || !depth_map)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    SweepArgs a{n, ray_idxs, stacked_views(ctx->p, features), P, P_inv, camera_center, nullptr,
+                nullptr, nullptr, nullptr, nullptr, Sp, nullptr, depth_map, points};
+    launch_sweep<0, false>(ctx, a, true, S(stream));
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+static int prefix_api(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                      const float *P, const float *P_inv, const float *cc, int32_t *rvi,
+                      int32_t *rvc, float *S_voxel, hipStream_t st) {
+    // raynet_fp.py:55-104: traversal (thread per ray), then sweep + mapping (wave per ray)
+    {
+        ProfScope prof(ctx, RN_K_TRAVERSE, n, st);
+        hipLaunchKernelGGL((k_traverse<false>), dim3(thread_blocks(n)), dim3(BLOCK), 0, st, ctx->p,
+                           n, ray_idxs, P_inv, cc, (const float *)nullptr, (const float *)nullptr,
+                           rvi, rvc);
+    }
+    RN_LAUNCH_CHECK(ctx);
+    SweepArgs a{n, ray_idxs, stacked_views(ctx->p, features), P, P_inv, cc, nullptr, nullptr,
+                nullptr, rvi, rvc, nullptr, S_voxel, nullptr, nullptr};
+    launch_sweep<1, false>(ctx, a, true, st);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_mvcnn_voxel_space(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                         const float *P, const float *P_inv, const float *camera_center,
+                         int32_t *rvi, int32_t *rvc, float *S_voxel, void *stream) {
+    if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !rvi ||
+        !rvc || !S_voxel)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    int rc = need_axes(ctx);
+    if (rc) return rc;
+    if (n == 0) return RN_OK;
+    return prefix_api(ctx, n, ray_idxs, features, P, P_inv, camera_center, rvi, rvc, S_voxel,
+                      S(stream));
+}
+
+int rn_mvcnn_voxel_space_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
+                               const float *features, const float *P, const float *P_inv,
+                               const float *camera_center, int32_t *rvi, int32_t *rvc,
+                               float *S_voxel, float *depth_map, void *stream) {
+    if (!depth_map) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    int rc = rn_mvcnn_voxel_space(ctx, n, ray_idxs, features, P, P_inv, camera_center, rvi, rvc,
+                                  S_voxel, stream);
+    if (rc || n == 0) return rc;
+    ProfScope prof(ctx, RN_K_DEPTH, n, S(stream));
+    hipLaunchKernelGGL((k_argmax_depth<false>), dim3(ray_blocks(n)), dim3(BLOCK), 0, S(stream),
+                       ctx->p, n, S_voxel, rvi, rvc, ctx->axes, camera_center, depth_map);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_fused_bp_sweep(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                      const float *P, const float *P_inv, const float *camera_center,
+                      int32_t *rvi, int32_t *rvc, float *S_voxel, const float *acc_in,
+                      const float *msgs_in, float *acc_out, float *msgs_out, void *stream) {
+    if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !rvi ||
+        !rvc || !S_voxel || !acc_in || !msgs_in || !acc_out || !msgs_out)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    int rc = need_axes(ctx);
+    if (rc) return rc;
+    if (n == 0) return RN_OK;
+    rc = prefix_api(ctx, n, ray_idxs, features, P, P_inv, camera_center, rvi, rvc, S_voxel,
+                    S(stream));
+    if (rc) return rc;
+    return launch_bp<false, true, false>(ctx, n, S_voxel, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
+                                  S(stream));
+}
+
+int rn_fused_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
+                   const float *P, const float *P_inv, const float *camera_center, int32_t *rvi,
+                   int32_t *rvc, float *S_voxel, const float *acc, const float *msgs,
+                   float *depth_map, void *stream) {
+    if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !rvi ||
+        !rvc || !S_voxel || !acc || !msgs || !depth_map)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    int rc = need_axes(ctx);
+    if (rc) return rc;
+    if (n == 0) return RN_OK;
+    rc = prefix_api(ctx, n, ray_idxs, features, P, P_inv, camera_center, rvi, rvc, S_voxel,
+                    S(stream));
+    if (rc) return rc;
+    // the reference overwrites S_voxel_space with the final distribution (raynet_fp.py:183-190)
+    return launch_depth<false, true>(ctx, n, S_voxel, rvi, rvc, acc, msgs, camera_center, S_voxel,
+                                     depth_map, S(stream));
+}
+
+// ------------------------------------------------------ resident-scene path
+int rn_acc_copies(const rn_ctx *ctx) { return ctx ? ctx->copies : 0; }
+
+int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
+                     const float *const *features_views_host, const float *P, const float *P_inv,
+                     const float *camera_center, int32_t *vox, int32_t *rvc, float *Sr,
+                     void *stream) {
+    if (!ctx || n < 0 || !ray_idxs || !features_views_host || !P || !P_inv || !camera_center ||
+        !vox || !rvc || !Sr)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    int rc = need_axes(ctx);
+    if (rc) return rc;
+    if (n == 0) return RN_OK;
+    FeatureViews fv;
+    for (int v = 0; v < MAX_VIEWS; v++) fv.v[v] = v < ctx->p.N ? features_views_host[v] : nullptr;
+    for (int v = 0; v < ctx->p.N; v++)
+        if (!fv.v[v]) return fail(ctx, RN_ERR_INVALID, "null feature map for view %d", v);
+    {
+        ProfScope prof(ctx, RN_K_TRAVERSE, n, S(stream));
+        hipLaunchKernelGGL((k_traverse<true>), dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream),
+                           ctx->p, n, ray_idxs, P_inv, camera_center, (const float *)nullptr,
+                           (const float *)nullptr, vox, rvc);
+    }
+    RN_LAUNCH_CHECK(ctx);
+    SweepArgs a{n, ray_idxs, fv, P, P_inv, camera_center, nullptr, nullptr, nullptr, vox, rvc,
+                nullptr, Sr, nullptr, nullptr};
+    launch_sweep<2, true>(ctx, a, true, S(stream));
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
+                      const int32_t *rvc, const float *acc_in, float *msgs, float *acc_part,
+                      void *stream) {
+    if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc_in || !msgs || !acc_part)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    if (ctx->acc_mode == 2)
+        return launch_bp<true, false, true>(ctx, n, Sr, vox, rvc, acc_in, msgs, acc_part, msgs, G,
+                                            S(stream));
+    return launch_bp<true, false, false>(ctx, n, Sr, vox, rvc, acc_in, msgs, acc_part, msgs,
+                                         ctx->acc_mode == 1 ? G : 0, S(stream));
+}
+
+int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream) {
+    if (!ctx || !acc_part || !acc_out) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    ProfScope prof(ctx, RN_K_ACC, 0, S(stream));
+    hipLaunchKernelGGL(k_acc_combine, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream), acc_part,
+                       ctx->copies, G, prior, acc_out, 1);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_acc_reduce_local(rn_ctx *ctx, float *acc_part, float *acc_out, void *stream) {
+    if (!ctx || !acc_part || !acc_out) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    ProfScope prof(ctx, RN_K_ACC, 0, S(stream));
+    hipLaunchKernelGGL(k_acc_combine, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream), acc_part,
+                       ctx->copies, G, 0.0f, acc_out, 0);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_acc_add_prior(rn_ctx *ctx, float *acc, float prior, void *stream) {
+    if (!ctx || !acc) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    hipLaunchKernelGGL(k_add_scalar, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream), acc, G,
+                       prior);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_scene_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
+                   const int32_t *rvc, const float *acc, const float *msgs,
+                   const float *camera_center, float *S_new, float *depth_map, void *stream) {
+    if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc || !msgs || (!S_new && !depth_map) ||
+        (depth_map && !camera_center))
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    int rc = need_axes(ctx);
+    if (rc) return rc;
+    if (n == 0) return RN_OK;
+    return launch_depth<true, false>(ctx, n, Sr, vox, rvc, acc, msgs, camera_center, S_new,
+                                     depth_map, S(stream));
+}
+
+int rn_prof_begin(rn_ctx *ctx, int32_t capacity) {
+    if (!ctx || capacity < 1) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (capacity > ctx->prof_cap) {
+        hipEvent_t *ev = new hipEvent_t[2 * capacity];
+        for (int i = 0; i < 2 * ctx->prof_cap; i++) ev[i] = ctx->prof_ev[i];
+        for (int i = 2 * ctx->prof_cap; i < 2 * capacity; i++) RN_HIP(ctx, hipEventCreate(&ev[i]));
+        delete[] ctx->prof_ev;
+        delete[] ctx->prof_id;
+        delete[] ctx->prof_rays;
+        ctx->prof_ev = ev;
+        ctx->prof_id = new int32_t[capacity];
+        ctx->prof_rays = new int32_t[capacity];
+        ctx->prof_cap = capacity;
+    }
+    ctx->prof_n = 0;
+    ctx->prof_on = true;
+    return RN_OK;
+}
+
+int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *n_rays_host,
+                float *ms_host) {
+    if (!ctx || !count) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    ctx->prof_on = false;
+    const int n = ctx->prof_n;
+    for (int i = 0; i < n; i++) {
+        RN_HIP(ctx, hipEventSynchronize(ctx->prof_ev[2 * i + 1]));
+        float ms = 0.0f;
+        RN_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        if (ms_host) ms_host[i] = ms;
+        if (kernel_ids_host) kernel_ids_host[i] = ctx->prof_id[i];
+        if (n_rays_host) n_rays_host[i] = ctx->prof_rays[i];
+    }
+    *count = n;
+    return RN_OK;
+}
+
+int rn_timer_start(rn_ctx *ctx, void *stream) {
+    if (!ctx) return RN_ERR_INVALID;
+    RN_HIP(ctx, hipEventRecord(ctx->ev0, S(stream)));
+    return RN_OK;
+}
+
+int rn_timer_stop(rn_ctx *ctx, void *stream, float *ms_out) {
+    if (!ctx || !ms_out) return RN_ERR_INVALID;
+    RN_HIP(ctx, hipEventRecord(ctx->ev1, S(stream)));
+    RN_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    RN_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+    return RN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,430 @@
+// raynet_kernels.h -- device code of the RayNet forward_pass hot path for gfx950.
+//
+// Execution model (MI355X-first, not the reference's one-thread-per-ray):
+//   * one 64-lane wavefront owns one ray; lanes stride the D depth planes and
+//     the <= M traversed voxels, so every per-ray column (similarities, voxel
+//     list, messages) is read and written as coalesced rows;
+//   * the sequential cumulative product / sum of the ray potential
+//     (mrf_bp.cu:115-167) are DPP wave scans with a carried prefix per 64-voxel
+//     chunk; the occupancy term is evaluated once per voxel instead of twice;
+//   * the D-deep cost column and the mapped voxel column live in LDS;
+//   * the only serial piece, the 3-D DDA (ray_tracing.pyx:64-199), runs one
+//     thread per ray in its own kernel and hands its list over in HBM.
+// Built with -ffp-contract=off: index maps are bit-exact w.r.t. the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+namespace rn {
+
+constexpr int WAVE = 64;
+constexpr int MAX_VIEWS = 16;
+
+struct Params {
+    int M, D, N, F, H, W, padding;
+    int gx, gy, gz;
+    int Hf, Wf;          // feature map extent: H+padding+1, W+padding+1
+    float bbox[6];
+};
+
+struct FeatureViews {
+    const float *v[MAX_VIEWS];   // one [Hf][Wf][F] map per view
+};
+
+// ----------------------------------------------------------------- wave ops
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                           __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xf,
+                                           false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+// row_shr:1,2,4,8 then row_bcast:15 / row_bcast:31 -- the gfx9 wave64 scan
+__device__ __forceinline__ float wave_scan_add(float x) {
+    x += dpp_f<0x111, 0xf>(0.0f, x);
+    x += dpp_f<0x112, 0xf>(0.0f, x);
+    x += dpp_f<0x114, 0xf>(0.0f, x);
+    x += dpp_f<0x118, 0xf>(0.0f, x);
+    x += dpp_f<0x142, 0xa>(0.0f, x);
+    x += dpp_f<0x143, 0xc>(0.0f, x);
+    return x;
+}
+__device__ __forceinline__ float wave_scan_mul(float x) {
+    x *= dpp_f<0x111, 0xf>(1.0f, x);
+    x *= dpp_f<0x112, 0xf>(1.0f, x);
+    x *= dpp_f<0x114, 0xf>(1.0f, x);
+    x *= dpp_f<0x118, 0xf>(1.0f, x);
+    x *= dpp_f<0x142, 0xa>(1.0f, x);
+    x *= dpp_f<0x143, 0xc>(1.0f, x);
+    return x;
+}
+__device__ __forceinline__ int wave_scan_max(int x) {
+    x = max(x, dpp_i<0x111, 0xf>(INT32_MIN, x));
+    x = max(x, dpp_i<0x112, 0xf>(INT32_MIN, x));
+    x = max(x, dpp_i<0x114, 0xf>(INT32_MIN, x));
+    x = max(x, dpp_i<0x118, 0xf>(INT32_MIN, x));
+    x = max(x, dpp_i<0x142, 0xa>(INT32_MIN, x));
+    x = max(x, dpp_i<0x143, 0xc>(INT32_MIN, x));
+    return x;
+}
+// value of the previous lane (wave_shr:1); lane 0 receives `first`
+__device__ __forceinline__ float wave_shift1(float x, float first) {
+    return dpp_f<0x138, 0xf>(first, x);
+}
+__device__ __forceinline__ float lane63(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ int lane63i(int x) { return __builtin_amdgcn_readlane(x, 63); }
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    return x;
+}
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// LDS hand-over between lanes of ONE wavefront: the hardware keeps a wave's DS
+// operations in order; this only stops the compiler from moving them.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float clampf(float x, float a, float b) {
+    return fminf(fmaxf(x, a), b);   // utils.cu:1-3
+}
+
+// ------------------------------------------------------------------- a1
+// sampling_schemes.cu:44-90; arithmetic identical to oracle rno_sample_in_bbox
+__device__ __forceinline__ void sample_in_bbox(const Params &p, int ray_idx,
+                                               const float *__restrict__ P_inv,
+                                               const float *__restrict__ cc, float s[3],
+                                               float e[3]) {
+    const float px = (float)(ray_idx / p.H);
+    const float py = (float)(ray_idx % p.H);
+    double o[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double a = 0.0;
+        a += (double)(P_inv[3 * r + 0] * px);
+        a += (double)(P_inv[3 * r + 1] * py);
+        a += (double)P_inv[3 * r + 2] * 1.0;
+        o[r] = a;
+    }
+    float dir[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) dir[i] = (float)(o[i] / o[3] - (double)cc[i]);
+    float t_near = -INFINITY, t_far = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float t1 = (float)(((double)p.bbox[i] - (double)cc[i]) / (double)dir[i]);
+        const float t2 = (float)(((double)p.bbox[3 + i] - (double)cc[i]) / (double)dir[i]);
+        t_near = fmaxf(fminf(t1, t2), t_near);
+        t_far = fminf(fmaxf(t1, t2), t_far);
+    }
+    const float near_mask = (fabsf(t_near) < fabsf(t_far)) ? 1.0f : 0.0f;
+    const float tn = t_near * near_mask + t_far * (1 - near_mask);
+    const float tf = (1 - near_mask) * t_near + near_mask * t_far;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        s[i] = cc[i] + tn * dir[i];
+        e[i] = cc[i] + tf * dir[i];
+    }
+}
+
+// ------------------------------------------------------------------- a2
+// feature_similarities.cu:10-61: project plane k of the ray into one view and
+// return the element offset of its feature vector inside that view's map
+__device__ __forceinline__ int feature_offset(const Params &p, const float *__restrict__ Pv,
+                                              const float point[3]) {
+    float x = 0.0f, y = 0.0f, n = 0.0f;
+    x += Pv[0] * point[0]; x += Pv[1] * point[1]; x += Pv[2] * point[2]; x += Pv[3] * 1;
+    y += Pv[4] * point[0]; y += Pv[5] * point[1]; y += Pv[6] * point[2]; y += Pv[7] * 1;
+    n += Pv[8] * point[0]; n += Pv[9] * point[1]; n += Pv[10] * point[2]; n += Pv[11] * 1;
+    x = x / n;
+    y = y / n;
+    const int half = (p.padding - 1) / 2;
+    int fx = (int)(roundf(x) + p.padding - half);   // v_cvt_i32_f32 saturates, NaN -> 0
+    int fy = (int)(roundf(y) + p.padding - half);
+    fx = min(max(fx, 0), p.W);
+    fy = min(max(fy, 0), p.H);
+    if (fx == 0 || fy == 0) fx = fy = 0;
+    return (fy * p.Wf + fx) * p.F;
+}
+
+__device__ __forceinline__ void plane_point(const float s[3], const float e[3], int k, int D,
+                                            float point[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) point[a] = s[a] + k * (e[a] - s[a]) / (D - 1);
+}
+
+// Generic plane sweep: lane = depth plane, the F-long dot is walked serially in
+// the reference's order (pairs i<j, then f), so it tracks the oracle to the
+// last bit before expf.  Any N, any F.  Writes raw pair sums / pairs to Sl[D].
+__device__ __forceinline__ void sweep_generic(const Params &p, const FeatureViews &fv,
+                                              const float *__restrict__ P, const float s[3],
+                                              const float e[3], int lane, float *Sl) {
+    const int pairs = (p.N * (p.N - 1)) / 2;
+    for (int base = 0; base < p.D; base += WAVE) {
+        const int k = base + lane;
+        if (k < p.D) {
+            float point[3];
+            plane_point(s, e, k, p.D, point);
+            float acc = 0.0f;
+            for (int i = 0; i < p.N; i++) {
+                const float *fi = fv.v[i] + feature_offset(p, P + 12 * i, point);
+                for (int j = i + 1; j < p.N; j++) {
+                    const float *fj = fv.v[j] + feature_offset(p, P + 12 * j, point);
+                    float dot = 0.0f;
+                    for (int f = 0; f < p.F; f++) dot += fi[f] * fj[f];
+                    acc += dot;
+                }
+            }
+            Sl[k] = acc / pairs;
+        }
+    }
+}
+
+// Cooperative plane sweep for F = 4*LPS: LPS lanes fetch one 16*LPS-byte feature
+// vector as one contiguous segment (a whole 128-B line for F=32), 64/LPS planes per
+// load instruction.  Each lane multiplies its 4 channels for all view pairs, the
+// LPS partial sums are folded with an xor butterfly.
+template <int NV, int LPS>
+__device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &fv,
+                                           const float *__restrict__ P, const float s[3],
+                                           const float e[3], int lane, float *Sl) {
+    constexpr int SPL = WAVE / LPS;       // planes per load instruction
+    const int sub = lane / LPS;           // which plane of the group
+    const int part = lane % LPS;          // which float4 of the vector
+    const int pairs = (NV * (NV - 1)) / 2;
+    for (int base = 0; base < p.D; base += WAVE) {
+        // lane k projects plane base+k into every view
+        int off[NV];
+        {
+            const int k = min(base + lane, p.D - 1);
+            float point[3];
+            plane_point(s, e, k, p.D, point);
+#pragma unroll
+            for (int v = 0; v < NV; v++) off[v] = feature_offset(p, P + 12 * v, point);
+        }
+        float mine = 0.0f;
+#pragma unroll 2
+        for (int it = 0; it < LPS; it++) {
+            const int src = it * SPL + sub;   // plane (within the chunk) this lane helps with
+            float4 f[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                const int o = __shfl(off[v], src);
+                f[v] = *reinterpret_cast<const float4 *>(fv.v[v] + o + 4 * part);
+            }
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+#pragma unroll
+                for (int j = i + 1; j < NV; j++) {
+                    float d = f[i].x * f[j].x;
+                    d += f[i].y * f[j].y;
+                    d += f[i].z * f[j].z;
+                    d += f[i].w * f[j].w;
+                    acc += d;
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < LPS; m <<= 1) acc += __shfl_xor(acc, m);
+            if (part == it) mine = acc;   // lane (sub, part) keeps plane part*SPL + sub
+        }
+        const int k = base + part * SPL + sub;
+        if (k < p.D) Sl[k] = mine / pairs;
+    }
+}
+
+// feature_similarities.cu:109-123 on the LDS column
+__device__ __forceinline__ void softmax_column(int D, int lane, float *Sl) {
+    float mx = -INFINITY;
+    for (int k = lane; k < D; k += WAVE) mx = fmaxf(mx, Sl[k]);
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int k = lane; k < D; k += WAVE) {
+        const float v = expf(Sl[k] - mx);
+        Sl[k] = v;
+        sum += v;
+    }
+    sum = wave_sum(sum);
+    for (int k = lane; k < D; k += WAVE) Sl[k] = Sl[k] / sum;
+}
+
+// ------------------------------------------------------------------- a3
+// ray_tracing.pyx:64-199, one thread per ray.  emit(i, x, y, z) stores voxel i.
+template <class Emit>
+__device__ __forceinline__ int dda(const Params &p, const float rs[3], const float re[3],
+                                   Emit emit) {
+    const float EPS = 1e-2f;
+    const int g[3] = {p.gx, p.gy, p.gz};
+    float s[3], e[3], bin[3], ray[3];
+    int step[3], cur[3], last[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        s[i] = rs[i] - p.bbox[i];
+        e[i] = re[i] - p.bbox[i];
+        bin[i] = (p.bbox[3 + i] - p.bbox[i]) / g[i];
+        ray[i] = e[i] - s[i];
+        step[i] = ray[i] >= 0 ? 1 : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        s[i] += step[i] * bin[i] * EPS;
+        e[i] -= step[i] * bin[i] * EPS;
+        cur[i] = (int)floorf(s[i] / bin[i]);
+        last[i] = (int)floorf(e[i] / bin[i]);
+    }
+    if (cur[0] < 0 || cur[0] >= g[0] || cur[1] < 0 || cur[1] >= g[1] || cur[2] < 0 ||
+        cur[2] >= g[2])
+        return 0;
+    float tm[3], td[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        tm[i] = FLT_MAX;
+        if (ray[i] != 0) {
+            const float c = cur[i] * bin[i];
+            float b;
+            if (step[i] < 0 && c < s[i])
+                b = c;
+            else
+                b = c + step[i] * bin[i];
+            tm[i] = (b - s[i]) / ray[i];
+        }
+        td[i] = ray[i] != 0 ? step[i] * bin[i] / ray[i] : FLT_MAX;
+    }
+    int cx = cur[0], cy = cur[1], cz = cur[2];
+    float tx = tm[0], ty = tm[1], tz = tm[2];
+    emit(0, cx, cy, cz);
+    int ii = 1;
+    while (!(cx == last[0] && cy == last[1] && cz == last[2]) && ii < p.M) {
+        if (tx < ty) {
+            if (tx < tz) {
+                cx += step[0];
+                if (cx < 0 || cx >= g[0]) return ii;
+                tx += td[0];
+            } else {
+                cz += step[2];
+                if (cz < 0 || cz >= g[2]) return ii;
+                tz += td[2];
+            }
+        } else {
+            if (ty < tz) {
+                cy += step[1];
+                if (cy < 0 || cy >= g[1]) return ii;
+                ty += td[1];
+            } else {
+                cz += step[2];
+                if (cz < 0 || cz >= g[2]) return ii;
+                tz += td[2];
+            }
+        }
+        emit(ii, cx, cy, cz);
+        ii++;
+    }
+    return ii;
+}
+
+// voxel list element access: the reference's [M][3] triples or the packed form
+template <bool PACKED>
+__device__ __forceinline__ void load_voxel(const int32_t *__restrict__ row, int i, int &x,
+                                           int &y, int &z) {
+    if (PACKED) {
+        const int v = row[i];
+        x = v >> 20;
+        y = (v >> 10) & 1023;
+        z = v & 1023;
+    } else {
+        x = row[3 * i];
+        y = row[3 * i + 1];
+        z = row[3 * i + 2];
+    }
+}
+__device__ __forceinline__ int pack_voxel(int x, int y, int z) {
+    return (x << 20) | (y << 10) | z;
+}
+
+// ------------------------------------------------------------------- a4
+// planes_voxels_mapping.cu:6-92 for one ray, wave-parallel.
+//   * t_i is computed per lane;
+//   * the reference's monotone (left, right) walk equals
+//       left_i = max_{j<=i} L(t_j),  L(t) = first l with !(t-l*step>0 && t-(l+1)*step>0),
+//     evaluated with the same fp32 expressions, so the plane indices are exact;
+//   * vals[] (LDS, M floats) receives the un-normalised interpolation, the sum
+//     is returned wave-uniform.
+template <bool PACKED>
+__device__ __forceinline__ float map_planes_to_voxels(const Params &p,
+                                                      const float *__restrict__ axes,
+                                                      const int32_t *__restrict__ vrow,
+                                                      int count, const float s[3],
+                                                      const float e[3], const float *Sl,
+                                                      float *vals, int lane) {
+    const float eps = 1e-4f;
+    float ray[3], ray_norm = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) ray[i] = e[i] - s[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) ray_norm += ray[i] * ray[i];
+    const float step = (1.0f - 0.0f) / (p.D - 1);
+    int carry = 0;
+    float total = 0.0f;
+    for (int base = 0; base < count; base += WAVE) {
+        const int i = base + lane;
+        const bool valid = i < count;
+        int L = 0;
+        float t = 0.0f;
+        if (valid) {
+            int x, y, z;
+            load_voxel<PACKED>(vrow, i, x, y, z);
+            float sum = 0.0f;
+            float vd = axes[x];
+            vd -= s[0];
+            sum += ray[0] * vd;
+            vd = axes[p.gx + y];
+            vd -= s[1];
+            sum += ray[1] * vd;
+            vd = axes[p.gx + p.gy + z];
+            vd -= s[2];
+            sum += ray[2] * vd;
+            t = clampf(sum / ray_norm, eps, 1 - eps);
+            L = max(0, (int)(t * (p.D - 1)) - 2);
+            while ((t - (0.0f + L * step) > 0) && (t - (0.0f + (L + 1) * step) > 0)) L++;
+        }
+        int left = max(wave_scan_max(valid ? L : 0), carry);
+        carry = lane63i(left);
+        float val = 0.0f;
+        if (valid) {
+            const int right = left + 1;
+            float left_d = fabsf(t - (0.0f + left * step));
+            float right_d = fabsf(t - (0.0f + right * step));
+            const float c1 = 1.0f - (left_d / (left_d + right_d));
+            const float c2 = 1.0f - (right_d / (left_d + right_d));
+            val = c1 * Sl[left] + c2 * Sl[right];
+            vals[i] = val;
+        }
+        total += val;
+    }
+    return wave_sum(total);
+}
+
+// ------------------------------------------------------------------ a5/a6
+__device__ __forceinline__ float occupancy_to_ray(float acc, float msg) {
+    // mrf_bp.cu:12-35
+    const float mu = acc - msg;
+    const float mx = fmaxf(0.0f, mu);
+    const float t1 = expf(0 - mx);
+    const float t2 = expf(mu - mx);
+    return clampf(t2 / (t1 + t2), 1e-4f, (float)(1 - 1e-4));
+}
+
+}  // namespace rn

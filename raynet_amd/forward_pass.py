@@ -1,0 +1,422 @@
+"""Forward-pass drivers -- mirror of raynet/forward_pass.py.
+
+`get_forward_pass_factory(name)` returns a class with the reference's constructor
+`(model, generation_params, sampling_scheme, image_shape, rays_batch,
+filter_out_rays=False)` whose `forward_pass(scene, (start, end, skip))` is a
+generator yielding one (H, W) float32 depth map per reference image
+(forward_pass.py:208-223, :744).
+
+RayNetForwardPass runs the schedule of forward_pass.py:579-748 (bp_iterations
+sweeps over all reference images, accumulator swap + prior refill, then a depth
+sweep) in one of two ways:
+
+  schedule="resident" (default, the MI355X-native path)
+      Features of every view are computed once; per reference image the K1 prefix
+      (sample, plane sweep, traversal, mapping, clip+renorm) runs once and its
+      per-ray columns stay in HBM together with the messages; each BP sweep and
+      the depth sweep stream them.  The reference recomputes all of it four
+      times and round-trips messages through a disk memmap.
+  schedule="reference"
+      Literal K1 / K2 launches per ray batch, everything recomputed per sweep,
+      like the reference (used by the parity tests and as an A/B in bench.py).
+
+Both give the same result (tests/test_forward_pass_gpu.py).  Decisions on the
+reference driver's quirks: messages persist across
+iterations (Q1) and every image uses its own messages in the depth sweep (Q2);
+`reference_quirks=True` reproduces the shipped behaviour instead.
+
+With torch.distributed initialised, the rays of every reference image are
+sharded contiguously over the ranks; each rank scatters into its own zeroed
+accumulator and one all-reduce (RCCL) per BP iteration merges them before the
+prior is added once.
+"""
+import numpy as np
+import torch
+
+from .hip_implementations import get_context
+from .hip_implementations.mvcnn_with_ray_marching_and_voxels_mapping import \
+    batch_mvcnn_voxel_traversal_with_ray_marching_with_depth_estimation
+from .hip_implementations.raynet_fp import perform_raynet_fp
+from .hip_implementations.similarities import \
+    perform_multi_view_cnn_forward_pass_with_depth_estimation
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous slice [lo, hi) of an n-long ray list owned by `rank`."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+class ForwardPass(object):
+    """forward_pass.py:25-223."""
+
+    def __init__(self, model, generation_params, sampling_scheme, image_shape,
+                 rays_batch=50000, filter_out_rays=False):
+        self._model = model
+        self._generation_params = generation_params
+        self._sampling_scheme = sampling_scheme
+        self.rays_batch = rays_batch
+        self._filter_out_rays = filter_out_rays
+        self._fp = None
+
+    def get_valid_rays_per_image(self, scene, i):
+        H, W = scene.image_shape
+        idxs = np.arange(H * W, dtype=np.int32)
+        if self._filter_out_rays:
+            idxs = idxs.reshape(W, H).T
+            G = scene.get_depth_map(i)
+            return idxs[G != 0].ravel()
+        return idxs
+
+    def _to_list_with_zeropadded_images(self, images, inputs=None):
+        # forward_pass.py:181-198
+        if inputs is None:
+            inputs = []
+        H, W, C = images[0].image.shape
+        p = self._generation_params.padding
+        for im in images:
+            zeropadded = np.zeros((H + 2 * p, W + 2 * p, C), dtype=np.float32)
+            zeropadded[p:p + H, p:p + W, :] = im.image
+            inputs.append(zeropadded)
+        return inputs
+
+    def _features(self, scene, ref_idx, images):
+        """(N, Hf, Wf, F) float32 CUDA tensor for [reference, neighbours...]."""
+        if hasattr(self._model, "view_features"):     # precomputed per-view maps
+            views = scene.view_indices_with_neighbors(ref_idx, self._generation_params.neighbors)
+            return torch.stack([self._model.view_features(scene, v).to("cuda", torch.float32)
+                                for v in views]).contiguous()
+        f = self._model.predict(np.stack(self._to_list_with_zeropadded_images(images), axis=0))
+        if not isinstance(f, torch.Tensor):
+            f = torch.from_numpy(np.ascontiguousarray(f, dtype=np.float32))
+        return f.to("cuda", torch.float32).contiguous()
+
+    def _camera_arrays(self, images):
+        P = np.ascontiguousarray(np.array([im.camera.P for im in images], dtype=np.float32))
+        P_inv = np.ascontiguousarray(images[0].camera.P_pinv, dtype=np.float32)
+        center = np.ascontiguousarray(images[0].camera.center, dtype=np.float32).ravel()
+        return P, P_inv, center
+
+    def forward_pass(self, scene, images_range):
+        raise NotImplementedError()
+
+
+class MultiViewCNNForwardPass(ForwardPass):
+    """forward_pass.py:226-344 (kernel K10)."""
+
+    def forward_pass(self, scene, images_range):
+        assert isinstance(images_range, tuple)
+        start, end, skip = images_range
+        gp = self._generation_params
+        H, W = scene.image_shape
+        B = self.rays_batch
+        ref_idx = start
+        while ref_idx < end:
+            ray_idxs = self.get_valid_rays_per_image(scene, ref_idx)
+            images = scene.get_image_with_neighbors(ref_idx, gp.neighbors)
+            features = self._features(scene, ref_idx, images)
+            F = features.shape[-1]
+            if self._fp is None:
+                self._fp = perform_multi_view_cnn_forward_pass_with_depth_estimation(
+                    gp.depth_planes, gp.neighbors + 1, F, H, W, gp.padding, scene.bbox.ravel(),
+                    self._sampling_scheme)
+            ctx = self._fp.context
+            P, P_inv, center = (ctx.dev(a) for a in self._camera_arrays(images))
+            ridx = ctx.dev(ray_idxs.astype(np.int32))
+            s = torch.zeros((min(B, len(ridx)), gp.depth_planes), dtype=torch.float32,
+                            device=ctx.device)
+            pts = torch.zeros((len(s), gp.depth_planes, 4), dtype=torch.float32,
+                              device=ctx.device)
+            depth_map = torch.zeros((H * W,), dtype=torch.float32, device=ctx.device)
+            for i in range(0, len(ridx), B):
+                self._fp(ridx[i:i + B], features, P, P_inv, center, s, pts, depth_map[i:i + B])
+            ref_idx += skip
+            yield depth_map.cpu().numpy().reshape(W, H).T
+
+
+class MultiViewCNNVoxelSpaceForwardPass(ForwardPass):
+    """forward_pass.py:347-485 (kernel K12)."""
+
+    def forward_pass(self, scene, images_range):
+        assert isinstance(images_range, tuple)
+        start, end, skip = images_range
+        gp = self._generation_params
+        H, W = scene.image_shape
+        M, B = gp.max_number_of_marched_voxels, self.rays_batch
+        vg = None
+        ref_idx = start
+        while ref_idx < end:
+            ray_idxs = self.get_valid_rays_per_image(scene, ref_idx)
+            images = scene.get_image_with_neighbors(ref_idx, gp.neighbors)
+            features = self._features(scene, ref_idx, images)
+            F = features.shape[-1]
+            if self._fp is None:
+                grid_shape = np.array(scene.voxel_grid(gp.grid_shape).shape[1:])
+                self._fp = batch_mvcnn_voxel_traversal_with_ray_marching_with_depth_estimation(
+                    M, gp.depth_planes, gp.neighbors + 1, F, H, W, gp.padding,
+                    scene.bbox.ravel(), grid_shape, self._sampling_scheme)
+            ctx = self._fp.context
+            if vg is None:
+                vg = ctx.dev(np.ascontiguousarray(
+                    scene.voxel_grid(gp.grid_shape).transpose(1, 2, 3, 0)))
+            P, P_inv, center = (ctx.dev(a) for a in self._camera_arrays(images))
+            ridx = ctx.dev(ray_idxs.astype(np.int32))
+            nb = min(B, len(ridx))
+            s = torch.zeros((nb, M), dtype=torch.float32, device=ctx.device)
+            rvi = torch.zeros((nb, M, 3), dtype=torch.int32, device=ctx.device)
+            rvc = torch.zeros((nb,), dtype=torch.int32, device=ctx.device)
+            depth_map = torch.zeros((H * W,), dtype=torch.float32, device=ctx.device)
+            for i in range(0, len(ridx), B):
+                s.zero_()
+                rvi.zero_()
+                rvc.zero_()
+                k = len(ridx[i:i + B])
+                self._fp(ridx[i:i + B], features, P, P_inv, center, vg, rvi[:k], rvc[:k], s[:k],
+                         depth_map[i:i + B])
+            ref_idx += skip
+            yield depth_map.cpu().numpy().reshape(W, H).T
+
+
+class RayNetForwardPass(ForwardPass):
+    """forward_pass.py:488-748."""
+
+    def __init__(self, model, generation_params, sampling_scheme, image_shape, rays_batch,
+                 filter_out_rays=False, bp_iterations=3, schedule="resident",
+                 reference_quirks=False, backend_factory=None):
+        super(RayNetForwardPass, self).__init__(model, generation_params, sampling_scheme,
+                                                image_shape, rays_batch, filter_out_rays)
+        assert schedule in ("resident", "reference")
+        self.bp_iterations = bp_iterations      # the reference hard-codes 3 (forward_pass.py:590)
+        self.schedule = schedule
+        self.reference_quirks = reference_quirks
+        # backend_factory(M, D, N, F, H, W, padding, bbox, grid_shape) -> object with the
+        # resident-scene methods of HipContext.  None = the HIP library.  (The
+        # world_size-2 gloo test injects a host stand-in to exercise the sharding and
+        # all-reduce logic without a GPU.)
+        self._backend_factory = backend_factory
+        self.ref_idx = -1
+        self._ctx = None
+        self._de = None
+        self.timings = {}
+        # state kept for inspection by tests / tools
+        self.accumulator = None
+        self.messages = {}
+        self.voxel_count = {}
+
+    # -- helpers -----------------------------------------------------------
+    def _context(self, scene, F):
+        if self._ctx is None:
+            gp = self._generation_params
+            H, W = scene.image_shape
+            grid_shape = np.array(scene.voxel_grid(gp.grid_shape).shape[1:])
+            if self._backend_factory is not None:
+                self._ctx = self._backend_factory(
+                    gp.max_number_of_marched_voxels, gp.depth_planes, gp.neighbors + 1, F, H, W,
+                    gp.padding, scene.bbox.ravel(), grid_shape)
+            else:
+                self._fp, self._de = perform_raynet_fp(
+                    gp.max_number_of_marched_voxels, gp.depth_planes, gp.neighbors + 1, F, H, W,
+                    gp.padding, scene.bbox.ravel(), grid_shape, self._sampling_scheme)
+                self._ctx = self._fp.context
+            self._vg = self._ctx.dev(np.ascontiguousarray(
+                scene.voxel_grid(gp.grid_shape).transpose(1, 2, 3, 0)))   # forward_pass.py:573-575
+            self._ctx.set_voxel_grid(self._vg)
+            self._ctx._grid_src = self._vg
+        return self._ctx
+
+    def _view_features(self, scene, ref_idxs):
+        """Per-view feature maps, each computed once: {view index: [Hf, Wf, F] tensor}."""
+        gp = self._generation_params
+        bank = {}
+        if hasattr(self._model, "view_features"):
+            for r in ref_idxs:
+                for v in scene.view_indices_with_neighbors(r, gp.neighbors):
+                    if v not in bank:
+                        bank[v] = self._model.view_features(scene, v)
+            return bank
+        for r in ref_idxs:
+            views = scene.view_indices_with_neighbors(r, gp.neighbors)
+            todo = [v for v in views if v not in bank]
+            if todo:
+                f = self._features(scene, r, [scene.get_image(v) for v in todo])
+                for k, v in enumerate(todo):
+                    bank[v] = f[k].contiguous()
+        return bank
+
+    def _prior(self):
+        gamma = self._generation_params.gamma_mrf
+        return float(np.float32(np.log(gamma) - np.log(1 - gamma)))
+
+    # -- the generator -------------------------------------------------------
+    def forward_pass(self, scene, images_range):
+        assert isinstance(images_range, tuple)
+        if self.schedule == "reference":
+            return self._forward_pass_reference(scene, images_range)
+        return self._forward_pass_resident(scene, images_range)
+
+    def _forward_pass_resident(self, scene, images_range):
+        start, end, skip = images_range
+        gp = self._generation_params
+        M = gp.max_number_of_marched_voxels
+        H, W = scene.image_shape
+        refs = list(range(start, end, skip))
+        dist, rank, world = _dist()
+
+        bank = self._view_features(scene, refs)
+        F = next(iter(bank.values())).shape[-1]
+        ctx = self._context(scene, F)
+        dev = ctx.device
+        bank = {v: f.to(dev, torch.float32).contiguous() for v, f in bank.items()}
+        prior = self._prior()
+        G = ctx.grid_shape
+        copies = ctx.acc_copies()
+        acc_in = torch.full(G, prior, dtype=torch.float32, device=dev)
+        acc_part = torch.zeros((copies,) + tuple(G), dtype=torch.float32, device=dev)
+        acc_next = torch.empty(G, dtype=torch.float32, device=dev)
+
+        # K1 prefix once per reference image; columns stay resident
+        per_image = {}
+        for r in refs:
+            ray_idxs = self.get_valid_rays_per_image(scene, r)
+            lo, hi = shard_bounds(len(ray_idxs), rank, world)
+            ridx = ctx.dev(np.ascontiguousarray(ray_idxs[lo:hi].astype(np.int32)))
+            n = len(ridx)
+            views = scene.view_indices_with_neighbors(r, gp.neighbors)
+            images = [scene.get_image(v) for v in views]
+            P, P_inv, center = (ctx.dev(a) for a in self._camera_arrays(images))
+            st = dict(ridx=ridx, n=n, lo=lo, hi=hi, total=len(ray_idxs), center=center,
+                      vox=torch.empty((n, M), dtype=torch.int32, device=dev),
+                      rvc=torch.empty((n,), dtype=torch.int32, device=dev),
+                      Sr=torch.empty((n, M), dtype=torch.float32, device=dev),
+                      msgs=torch.zeros((n, M), dtype=torch.float32, device=dev))
+            B = self.rays_batch if self.rays_batch else n
+            for i in range(0, n, B):
+                ctx.scene_prepare(ridx[i:i + B], [bank[v] for v in views], P, P_inv, center,
+                                  st["vox"][i:i + B], st["rvc"][i:i + B], st["Sr"][i:i + B])
+            per_image[r] = st
+
+        for it in range(self.bp_iterations):
+            for r in refs:
+                st = per_image[r]
+                if self.reference_quirks and it > 0:
+                    st["msgs"].zero_()       # memmap reopened with mode="w+" 
+                n = st["n"]
+                B = self.rays_batch if self.rays_batch else n
+                for i in range(0, n, B):
+                    ctx.scene_bp_sweep(st["Sr"][i:i + B], st["vox"][i:i + B], st["rvc"][i:i + B],
+                                       acc_in, st["msgs"][i:i + B], acc_part)
+            # swap + prior refill of forward_pass.py:676-678; across ranks the prior is
+            # added once, after the sum
+            if world > 1:
+                ctx.acc_reduce_local(acc_part, acc_next)
+                dist.all_reduce(acc_next, op=dist.ReduceOp.SUM)
+                ctx.acc_add_prior(acc_next, prior)
+            else:
+                ctx.acc_combine(acc_part, prior, acc_next)
+            acc_in, acc_next = acc_next, acc_in
+        self.accumulator = acc_in
+
+        last = per_image[refs[-1]] if refs else None
+        for r in refs:
+            st = per_image[r]
+            msgs = st["msgs"]
+            if self.reference_quirks and last is not None and last["n"] == st["n"]:
+                msgs = last["msgs"]          # the loop variable leaks
+            depth = torch.zeros((st["total"],), dtype=torch.float32, device=dev)
+            n = st["n"]
+            B = self.rays_batch if self.rays_batch else n
+            for i in range(0, n, B):
+                ctx.scene_depth(st["Sr"][i:i + B], st["vox"][i:i + B], st["rvc"][i:i + B],
+                                acc_in, msgs[i:i + B], st["center"], None,
+                                depth[st["lo"] + i:st["lo"] + min(i + B, n)])
+            if world > 1:
+                dist.all_reduce(depth, op=dist.ReduceOp.SUM)   # disjoint slices, zeros elsewhere
+            self.messages[r] = st["msgs"]
+            self.voxel_count[r] = st["rvc"]
+            self.ref_idx = r
+            if self._filter_out_rays:
+                full = np.zeros((H * W,), dtype=np.float32)
+                full[self.get_valid_rays_per_image(scene, r)] = depth.cpu().numpy()
+                yield full.reshape(W, H).T
+            else:
+                yield depth.cpu().numpy().reshape(W, H).T
+
+    def _forward_pass_reference(self, scene, images_range):
+        """Literal schedule of forward_pass.py:579-748 with K1 / K2 (single rank)."""
+        start, end, skip = images_range
+        gp = self._generation_params
+        M = gp.max_number_of_marched_voxels
+        H, W = scene.image_shape
+        refs = list(range(start, end, skip))
+        prior = self._prior()
+        msgs_all = {}
+        ctx = None
+        acc = acc_out = None
+        for it in range(self.bp_iterations):
+            for r in refs:
+                ray_idxs = self.get_valid_rays_per_image(scene, r)
+                images = scene.get_image_with_neighbors(r, gp.neighbors)
+                features = self._features(scene, r, images)
+                ctx = self._context(scene, features.shape[-1])
+                if acc is None:
+                    acc = torch.full(ctx.grid_shape, prior, dtype=torch.float32, device=ctx.device)
+                    acc_out = torch.full(ctx.grid_shape, prior, dtype=torch.float32,
+                                         device=ctx.device)
+                P, P_inv, center = (ctx.dev(a) for a in self._camera_arrays(images))
+                ridx = ctx.dev(ray_idxs.astype(np.int32))
+                B = self.rays_batch if self.rays_batch else len(ridx)
+                B = min(B, len(ridx))
+                if r not in msgs_all or (self.reference_quirks and it > 0):
+                    msgs_all[r] = torch.zeros((len(ridx), M), dtype=torch.float32,
+                                              device=ctx.device)
+                s = torch.zeros((B, M), dtype=torch.float32, device=ctx.device)
+                rvi = torch.zeros((B, M, 3), dtype=torch.int32, device=ctx.device)
+                rvc = torch.zeros((B,), dtype=torch.int32, device=ctx.device)
+                for i in range(0, len(ridx), B):
+                    s.zero_()
+                    rvi.zero_()
+                    rvc.zero_()              # forward_pass.py:646-648
+                    k = len(ridx[i:i + B])
+                    self._fp(ridx[i:i + B], features, P, P_inv, center, self._vg, rvi[:k], rvc[:k],
+                             s[:k], acc, msgs_all[r][i:i + B], acc_out)
+            acc_out, acc = acc, acc_out
+            acc_out.fill_(prior)             # forward_pass.py:676-678
+        self.accumulator = acc
+        for r in refs:
+            ray_idxs = self.get_valid_rays_per_image(scene, r)
+            images = scene.get_image_with_neighbors(r, gp.neighbors)
+            features = self._features(scene, r, images)
+            P, P_inv, center = (ctx.dev(a) for a in self._camera_arrays(images))
+            ridx = ctx.dev(ray_idxs.astype(np.int32))
+            B = min(self.rays_batch if self.rays_batch else len(ridx), len(ridx))
+            msgs = msgs_all[refs[-1]] if self.reference_quirks else msgs_all[r]
+            s = torch.zeros((B, M), dtype=torch.float32, device=ctx.device)
+            rvi = torch.zeros((B, M, 3), dtype=torch.int32, device=ctx.device)
+            rvc = torch.zeros((B,), dtype=torch.int32, device=ctx.device)
+            depth = torch.zeros((H * W,), dtype=torch.float32, device=ctx.device)
+            for i in range(0, len(ridx), B):
+                s.zero_()
+                rvi.zero_()
+                rvc.zero_()
+                k = len(ridx[i:i + B])
+                self._de(ridx[i:i + B], features, P, P_inv, center, self._vg, rvi[:k], rvc[:k],
+                         s[:k], acc, msgs[i:i + B], depth[i:i + B])
+            self.messages[r] = msgs_all[r]
+            self.ref_idx = r
+            yield depth.cpu().numpy().reshape(W, H).T
+
+
+def get_forward_pass_factory(name):
+    # forward_pass.py:859-865.  "hartmann_fp" (a different network, not on the path)
+    # is not provided.
+    return {
+        "multi_view_cnn": MultiViewCNNForwardPass,
+        "multi_view_cnn_voxel_space": MultiViewCNNVoxelSpaceForwardPass,
+        "raynet": RayNetForwardPass,
+    }[name]

@@ -1,0 +1,222 @@
+"""HipContext: one rn_ctx (include/raynet_hip.h) plus the torch plumbing.
+
+The reference compiles one PyCUDA module per (M, D, N, F, H, W, padding, bbox,
+grid_shape) tuple (cuda_implementations/raynet_fp.py:230-248); here the same
+tuple creates one context and the kernels take the sizes at run time.  torch is
+used for device memory and streams only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def to_device(x, dtype=None, device="cuda"):
+    """The reference's `to_gpu` / all_arrays_to_gpu (cuda_implementations/utils.py:11-22):
+    NumPy arrays are uploaded, device tensors pass through untouched."""
+    if isinstance(x, torch.Tensor):
+        t = x
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        if not t.is_cuda:
+            t = t.to(device)
+        return t.contiguous()
+    a = np.ascontiguousarray(x)
+    t = torch.from_numpy(a)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to(device)
+
+
+class HipContext(object):
+    def __init__(self, M, D, N, F, H, W, padding, bbox, grid_shape, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.RaynetHipError(
+                "no GPU visible: raynet_amd runs its hot path on MI355X only (no CPU fallback)")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None
+                                   else device)
+        bbox = np.asarray(bbox, dtype=np.float32).reshape(-1)
+        assert bbox.shape == (6,)
+        grid_shape = [int(g) for g in np.asarray(grid_shape).reshape(-1)]
+        assert len(grid_shape) == 3
+        cfg = _lib.Config()
+        cfg.M, cfg.D, cfg.N, cfg.F = int(M), int(D), int(N), int(F)
+        cfg.H, cfg.W, cfg.padding = int(H), int(W), int(padding)
+        for i in range(3):
+            cfg.grid[i] = grid_shape[i]
+        for i in range(6):
+            cfg.bbox[i] = float(bbox[i])
+        cfg.device = self.device.index
+        self.M, self.D, self.N, self.F = int(M), int(D), int(N), int(F)
+        self.H, self.W, self.padding = int(H), int(W), int(padding)
+        self.bbox = bbox
+        self.grid_shape = tuple(grid_shape)
+        self.G = grid_shape[0] * grid_shape[1] * grid_shape[2]
+        self.feature_shape = (self.N, self.H + self.padding + 1, self.W + self.padding + 1, self.F)
+        handle = ctypes.c_void_p()
+        rc = self.lib.rn_create(ctypes.byref(cfg), ctypes.byref(handle))
+        if rc != _lib.RN_OK:
+            raise _lib.RaynetHipError("rn_create failed: %s" % _lib.STATUS.get(rc, rc))
+        self._h = handle
+        self._grid_set = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.rn_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != _lib.RN_OK:
+            raise _lib.RaynetHipError("%s: %s" % (
+                _lib.STATUS.get(rc, rc), self.lib.rn_last_error(self._h).decode()))
+
+    def dev(self, x, dtype=None):
+        return to_device(x, dtype, self.device)
+
+    def set_voxel_grid(self, voxel_grid):
+        vg = self.dev(voxel_grid, torch.float32)
+        assert vg.numel() == self.G * 3
+        self._check(self.lib.rn_set_voxel_grid(self._h, _ptr(vg), _stream()))
+        self._grid_set = True
+        self._vg_keepalive = vg
+
+    def acc_copies(self):
+        return int(self.lib.rn_acc_copies(self._h))
+
+    # -- timing (bench.py): hipEvents on the stream the kernels run on ------
+    def timer_start(self):
+        self._check(self.lib.rn_timer_start(self._h, _stream()))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        self._check(self.lib.rn_timer_stop(self._h, _stream(), ctypes.byref(ms)))
+        return float(ms.value)
+
+    KERNEL_NAMES = {1: "traverse", 2: "sweep_map", 3: "bp", 4: "depth", 5: "acc", 6: "other"}
+
+    def prof_begin(self, capacity=4096):
+        self._prof_cap = capacity
+        self._check(self.lib.rn_prof_begin(self._h, capacity))
+
+    def prof_end(self):
+        """-> list of (kernel name, n_rays, milliseconds), one per launch."""
+        cap = self._prof_cap
+        ids = (ctypes.c_int32 * cap)()
+        rays = (ctypes.c_int32 * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = ctypes.c_int32()
+        self._check(self.lib.rn_prof_end(self._h, ctypes.byref(n), ids, rays, ms))
+        return [(self.KERNEL_NAMES.get(ids[i], str(ids[i])), int(rays[i]), float(ms[i]))
+                for i in range(n.value)]
+
+    # -- thin wrappers; argument order is the header's ------------------------
+    def fill_f32(self, t, value):
+        self._check(self.lib.rn_fill_f32(self._h, _ptr(t), t.numel(), float(value), _stream()))
+
+    def fill_i32(self, t, value):
+        self._check(self.lib.rn_fill_i32(self._h, _ptr(t), t.numel(), int(value), _stream()))
+
+    def sample_rays(self, ray_idxs, P_inv, center, starts, ends):
+        self._check(self.lib.rn_sample_rays(self._h, len(ray_idxs), _ptr(ray_idxs), _ptr(P_inv),
+                                            _ptr(center), _ptr(starts), _ptr(ends), _stream()))
+
+    def sample_points(self, ray_idxs, P_inv, center, points):
+        self._check(self.lib.rn_sample_points(self._h, len(ray_idxs), _ptr(ray_idxs), _ptr(P_inv),
+                                              _ptr(center), _ptr(points), _stream()))
+
+    def compute_similarities(self, features, P, starts, ends, S):
+        self._check(self.lib.rn_compute_similarities(self._h, len(starts), _ptr(features), _ptr(P),
+                                                     _ptr(starts), _ptr(ends), _ptr(S), _stream()))
+
+    def voxel_traversal(self, starts, ends, rvi, rvc):
+        self._check(self.lib.rn_voxel_traversal(self._h, len(starts), _ptr(starts), _ptr(ends),
+                                                _ptr(rvi), _ptr(rvc), _stream()))
+
+    def planes_to_voxels(self, rvi, rvc, starts, ends, S, S_new):
+        self._check(self.lib.rn_planes_to_voxels(self._h, len(rvc), _ptr(rvi), _ptr(rvc),
+                                                 _ptr(starts), _ptr(ends), _ptr(S), _ptr(S_new),
+                                                 _stream()))
+
+    def bp_sweep(self, S, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out):
+        self._check(self.lib.rn_bp_sweep(self._h, len(rvc), _ptr(S), _ptr(rvi), _ptr(rvc),
+                                         _ptr(acc_in), _ptr(msgs_in), _ptr(acc_out),
+                                         _ptr(msgs_out), _stream()))
+
+    def depth_estimation(self, S, rvi, rvc, acc, msgs, S_new):
+        self._check(self.lib.rn_depth_estimation(self._h, len(rvc), _ptr(S), _ptr(rvi), _ptr(rvc),
+                                                 _ptr(acc), _ptr(msgs), _ptr(S_new), _stream()))
+
+    def mvcnn_similarities(self, ray_idxs, features, P, P_inv, center, S):
+        self._check(self.lib.rn_mvcnn_similarities(self._h, len(ray_idxs), _ptr(ray_idxs),
+                                                   _ptr(features), _ptr(P), _ptr(P_inv),
+                                                   _ptr(center), _ptr(S), _stream()))
+
+    def mvcnn_depth(self, ray_idxs, features, P, P_inv, center, S, points, depth_map):
+        self._check(self.lib.rn_mvcnn_depth(self._h, len(ray_idxs), _ptr(ray_idxs), _ptr(features),
+                                            _ptr(P), _ptr(P_inv), _ptr(center), _ptr(S),
+                                            _ptr(points), _ptr(depth_map), _stream()))
+
+    def mvcnn_voxel_space(self, ray_idxs, features, P, P_inv, center, rvi, rvc, S_voxel,
+                          depth_map=None):
+        if depth_map is None:
+            self._check(self.lib.rn_mvcnn_voxel_space(
+                self._h, len(ray_idxs), _ptr(ray_idxs), _ptr(features), _ptr(P), _ptr(P_inv),
+                _ptr(center), _ptr(rvi), _ptr(rvc), _ptr(S_voxel), _stream()))
+        else:
+            self._check(self.lib.rn_mvcnn_voxel_space_depth(
+                self._h, len(ray_idxs), _ptr(ray_idxs), _ptr(features), _ptr(P), _ptr(P_inv),
+                _ptr(center), _ptr(rvi), _ptr(rvc), _ptr(S_voxel), _ptr(depth_map), _stream()))
+
+    def fused_bp_sweep(self, ray_idxs, features, P, P_inv, center, rvi, rvc, S_voxel, acc_in,
+                       msgs_in, acc_out, msgs_out):
+        self._check(self.lib.rn_fused_bp_sweep(
+            self._h, len(ray_idxs), _ptr(ray_idxs), _ptr(features), _ptr(P), _ptr(P_inv),
+            _ptr(center), _ptr(rvi), _ptr(rvc), _ptr(S_voxel), _ptr(acc_in), _ptr(msgs_in),
+            _ptr(acc_out), _ptr(msgs_out), _stream()))
+
+    def fused_depth(self, ray_idxs, features, P, P_inv, center, rvi, rvc, S_voxel, acc, msgs,
+                    depth_map):
+        self._check(self.lib.rn_fused_depth(
+            self._h, len(ray_idxs), _ptr(ray_idxs), _ptr(features), _ptr(P), _ptr(P_inv),
+            _ptr(center), _ptr(rvi), _ptr(rvc), _ptr(S_voxel), _ptr(acc), _ptr(msgs),
+            _ptr(depth_map), _stream()))
+
+    # -- resident-scene path ---------------------------------------------------
+    def scene_prepare(self, ray_idxs, feature_views, P, P_inv, center, vox, rvc, Sr):
+        assert len(feature_views) == self.N
+        arr = (ctypes.c_void_p * self.N)(*[fv.data_ptr() for fv in feature_views])
+        self._check(self.lib.rn_scene_prepare(self._h, len(ray_idxs), _ptr(ray_idxs), arr, _ptr(P),
+                                              _ptr(P_inv), _ptr(center), _ptr(vox), _ptr(rvc),
+                                              _ptr(Sr), _stream()))
+
+    def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part):
+        self._check(self.lib.rn_scene_bp_sweep(self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc),
+                                               _ptr(acc_in), _ptr(msgs), _ptr(acc_part), _stream()))
+
+    def acc_combine(self, acc_part, prior, acc_out):
+        self._check(self.lib.rn_acc_combine(self._h, _ptr(acc_part), float(prior), _ptr(acc_out),
+                                            _stream()))
+
+    def acc_reduce_local(self, acc_part, acc_out):
+        self._check(self.lib.rn_acc_reduce_local(self._h, _ptr(acc_part), _ptr(acc_out), _stream()))
+
+    def acc_add_prior(self, acc, prior):
+        self._check(self.lib.rn_acc_add_prior(self._h, _ptr(acc), float(prior), _stream()))
+
+    def scene_depth(self, Sr, vox, rvc, acc, msgs, center, S_new, depth_map):
+        self._check(self.lib.rn_scene_depth(self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc),
+                                            _ptr(acc), _ptr(msgs), _ptr(center), _ptr(S_new),
+                                            _ptr(depth_map), _stream()))

@@ -1,0 +1,95 @@
+"""CPU-side checks of the drop-in boundary: libraynet_hip.so builds for gfx950, loads,
+and exports every symbol include/raynet_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "raynet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from raynet_amd import _lib
+    path = _lib.build()
+    lib = ctypes.CDLL(path)
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+    assert sorted(_lib.SIGNATURES) == names     # the ctypes table covers the whole header
+    _lib.load()
+    assert lib.rn_version
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    """Without a GPU the product refuses to run (there is no CPU route)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from raynet_amd import _lib
+    from raynet_amd.hip_implementations.context import HipContext
+    with pytest.raises(_lib.RaynetHipError):
+        HipContext(32, 8, 2, 4, 8, 8, 3, (0, 0, 0, 1, 1, 1), (4, 4, 4))
+    lib = _lib.load()
+    cfg = _lib.Config()
+    cfg.M, cfg.D, cfg.N, cfg.F, cfg.H, cfg.W, cfg.padding = 32, 8, 2, 4, 8, 8, 3
+    for i in range(3):
+        cfg.grid[i] = 4
+        cfg.bbox[3 + i] = 1.0
+    h = ctypes.c_void_p()
+    assert lib.rn_create(ctypes.byref(cfg), ctypes.byref(h)) == -3     # RN_ERR_NO_DEVICE
+
+
+def test_product_package_never_touches_the_oracle():
+    """raynet_amd must not import / link / open anything under oracle/ (comments may
+    mention it)."""
+    bad = re.compile(r"(^|\s)(import|from)\s+oracle\b|libraynet_oracle|oracle/|oracle\.\w+\(|rno_\w+\(",
+                     re.M)
+    pkg = os.path.join(REPO, "raynet_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                m = bad.search(src)
+                assert m is None, "%s references the oracle: %r" % (f, m.group(0))
+
+
+def test_host_side_mirrors_reference_names():
+    from raynet_amd.common.generation_parameters import GenerationParameters
+    from raynet_amd.forward_pass import (ForwardPass, MultiViewCNNForwardPass,
+                                         MultiViewCNNVoxelSpaceForwardPass, RayNetForwardPass,
+                                         get_forward_pass_factory, shard_bounds)
+    assert get_forward_pass_factory("raynet") is RayNetForwardPass
+    assert get_forward_pass_factory("multi_view_cnn") is MultiViewCNNForwardPass
+    assert get_forward_pass_factory("multi_view_cnn_voxel_space") is MultiViewCNNVoxelSpaceForwardPass
+    assert issubclass(RayNetForwardPass, ForwardPass)
+    gp = GenerationParameters()
+    assert gp.depth_planes == 32 and gp.neighbors == 4 and gp.max_number_of_marched_voxels == 400
+    # every ray owned by exactly one rank, in order
+    for n in (0, 1, 7, 307200):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+
+
+def test_scene_shim_conventions():
+    import numpy as np
+    from raynet_amd.common.scene import adjacent_views, get_voxel_grid
+    from oracle.oracle import voxel_grid_centers
+    g = get_voxel_grid(np.array([[-1, -1, -1, 1, 1, 1]], np.float32), (8, 4, 2))
+    assert g.shape == (3, 8, 4, 2) and g.dtype == np.float32
+    assert np.array_equal(np.ascontiguousarray(g.transpose(1, 2, 3, 0)),
+                          voxel_grid_centers([-1, -1, -1, 1, 1, 1], (8, 4, 2)))
+    assert np.allclose(g[0, :, 0, 0], -1 + (np.arange(8) + 0.5) * 0.25)
+    assert adjacent_views(0, 12, 4) == [1, 2, 3, 4]
+    assert adjacent_views(11, 12, 4) == [7, 8, 9, 10]
+    assert adjacent_views(5, 12, 4) == [3, 4, 6, 7]
+    assert adjacent_views(2, 5, 4) == [0, 1, 3, 4]

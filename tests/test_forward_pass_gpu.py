@@ -1,0 +1,183 @@
+"""RayNetForwardPass (the reference's ForwardPass API) on the GPU: the resident
+schedule vs the literal K1/K2 schedule vs the oracle, the MV-CNN twin as model, the
+other two drivers, and size-independent properties at BASELINE.json's full size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no CPU fallback exists)"
+    from raynet_amd import _lib
+    _lib.build()
+    return torch
+
+
+def _gp(D, M, grid, neighbors=4, padding=11):
+    from raynet_amd.common.generation_parameters import GenerationParameters
+    return GenerationParameters(depth_planes=D, neighbors=neighbors,
+                                grid_shape=np.array(grid, np.int32),
+                                max_number_of_marched_voxels=M, padding=padding, gamma_mrf=0.05)
+
+
+def _oracle_forward(oracle_mod, scene, bank, gp, refs, H, W, iters=3, quirks=False):
+    o = oracle_mod.Oracle(M=gp.max_number_of_marched_voxels, D=gp.depth_planes,
+                          N=gp.neighbors + 1, F=32, H=H, W=W, padding=gp.padding,
+                          bbox=scene.bbox.ravel(), grid_shape=gp.grid_shape,
+                          threads=oracle_mod.Oracle.max_threads())
+    vg = oracle_mod.voxel_grid_centers(scene.bbox.ravel(), gp.grid_shape)
+    ridx = np.arange(H * W, dtype=np.int32)
+    cams = {}
+    for r in refs:
+        views = scene.view_indices_with_neighbors(r, gp.neighbors)
+        cams[r] = (bank.stacked(views).cpu().numpy(),
+                   np.array([scene.get_image(v).camera.P for v in views], np.float32),
+                   scene.get_image(r).camera.P_pinv.astype(np.float32),
+                   scene.get_image(r).camera.center.ravel().astype(np.float32))
+    acc = o.prior(0.05)
+    msgs = {r: np.zeros((H * W, o.M), np.float32) for r in refs}
+    for it in range(iters):
+        out = o.prior(0.05)
+        for r in refs:
+            if quirks and it > 0:
+                msgs[r][...] = 0
+            f, P, Pi, c = cams[r]
+            o.fused_bp(ridx, f, P, Pi, c, vg, acc, msgs[r], out)
+        acc = out
+    depths, dists = [], []
+    for r in refs:
+        f, P, Pi, c = cams[r]
+        m = msgs[refs[-1]] if quirks else msgs[r]
+        _, _, S_new, depth = o.fused_depth(ridx, f, P, Pi, c, vg, acc, m)
+        depths.append(depth.reshape(W, H).T)
+        dists.append(S_new)
+    return acc, msgs, depths, dists
+
+
+def _depth_close(a, b, dist=None, W=None, H=None):
+    """<= 1e-4 everywhere except arg-max near-ties (a 1-ulp change flips a voxel)."""
+    d = np.abs(a - b)
+    bad = d > 1e-4
+    if dist is not None and bad.any():
+        top = np.sort(dist, axis=1)[:, -2:]
+        gap = (top[:, 1] - top[:, 0]).reshape(W, H).T
+        assert np.all(gap[bad] <= 5e-5), "depth differs away from a tie"
+    return bad.mean()
+
+
+@pytest.mark.parametrize("quirks", [False, True])
+def test_resident_vs_reference_schedule_vs_oracle(torch, oracle_mod, quirks):
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W, D, M, grid = 24, 32, 16, 96, (32, 32, 32)
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(D, M, grid)
+    refs = (0, 3, 1)
+    cls = get_forward_pass_factory("raynet")
+    fa = cls(bank, gp, "sample_in_bbox", (H, W), 300, reference_quirks=quirks)
+    da = list(fa.forward_pass(scene, refs))
+    fb = cls(bank, gp, "sample_in_bbox", (H, W), 300, schedule="reference",
+             reference_quirks=quirks)
+    db = list(fb.forward_pass(scene, refs))
+    assert len(da) == len(db) == 3 and da[0].shape == (H, W) and da[0].dtype == np.float32
+    acc_o, msgs_o, depth_o, dist_o = _oracle_forward(oracle_mod, scene, bank, gp, [0, 1, 2], H, W,
+                                                     quirks=quirks)
+    acc_a, acc_b = fa.accumulator.cpu().numpy(), fb.accumulator.cpu().numpy()
+    assert np.abs(acc_a - acc_b).max() < 2e-3
+    assert np.abs(acc_a - acc_o).max() < 5e-3
+    for i, r in enumerate([0, 1, 2]):
+        assert _depth_close(da[i], depth_o[i], dist_o[i], W, H) <= 0.01
+        assert _depth_close(db[i], depth_o[i], dist_o[i], W, H) <= 0.01
+        m = fa.messages[r].cpu().numpy()
+        tol = 1e-4 + 64 * 2.0 ** -24 * np.exp(np.minimum(np.abs(msgs_o[r]), 17.0))
+        assert np.all(np.abs(m - msgs_o[r]) <= tol)
+
+
+def test_mvcnn_twin_as_model_and_other_drivers(torch, oracle_mod):
+    """End to end with the PyTorch MV-CNN twin producing the features
+    (models.py:90-111 architecture), through all three drivers."""
+    from raynet_amd.common.camera import Camera
+    from raynet_amd.common.scene import Image, Scene
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.models import get_nn
+    from raynet_amd.synthetic import ring_cameras
+    H, W = 20, 28
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    cams = ring_cameras(5, H, W, focal=1.5 * H)
+    scene = Scene([Image(rng.random((H, W, 3)).astype(np.float32), c) for c in cams],
+                  [-1, -1, -1, 1, 1, 1])
+    model = get_nn("simple_cnn")().cuda()
+    gp = _gp(16, 64, (16, 16, 16))
+    feats = model.predict(np.zeros((1, H + 22, W + 22, 3), np.float32))
+    assert tuple(feats.shape) == (1, H + 12, W + 12, 32)     # H + padding + 1
+    out = {}
+    for name in ("multi_view_cnn", "multi_view_cnn_voxel_space", "raynet"):
+        fp = get_forward_pass_factory(name)(model, gp, "sample_in_bbox", (H, W), 1000)
+        out[name] = list(fp.forward_pass(scene, (0, 2, 1)))
+        assert len(out[name]) == 2
+        for d in out[name]:
+            assert d.shape == (H, W) and d.dtype == np.float32 and np.isfinite(d).all()
+            assert (d > 1.0).all() and (d < 6.0).all()      # camera ring radius 3, box +-1
+
+
+def test_full_size_properties(torch):
+    """BASELINE.json config 2 size (480x640 rays, 64 planes, 128^3, M=384), two
+    reference images: size-independent properties of the path."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W, D, M, grid = 480, 640, 64, 384, (128, 128, 128)
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(D, M, grid)
+    fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 130000)
+    depths = list(fp.forward_pass(scene, (0, 2, 1)))
+    ctx = fp._ctx
+    acc = fp.accumulator
+    assert torch.isfinite(acc).all()
+    for r in (0, 1):
+        rvc = fp.voxel_count[r]
+        msgs = fp.messages[r]
+        assert int(rvc.min()) >= 0 and int(rvc.max()) <= M
+        assert torch.isfinite(msgs).all()
+        # nothing is written beyond a ray's count
+        idx = torch.arange(M, device="cuda")[None, :]
+        assert float(msgs[idx >= rvc[:, None]].abs().max()) == 0.0
+        d = depths[r]
+        assert d.shape == (H, W) and np.isfinite(d).all()
+    # planted sphere of radius 0.6 at the origin, camera 0 at distance ~3.015: the centre
+    # pixel's depth is the distance to the sphere's front, within a couple of voxels
+    c0 = np.linalg.norm(scene.get_image(0).camera.center.ravel()[:3])
+    centre = depths[0][H // 2 - 4:H // 2 + 4, W // 2 - 4:W // 2 + 4]
+    assert np.abs(np.median(centre) - (c0 - 0.6)) < 0.06
+    # voxel lists: consecutive voxels differ by one step along exactly one axis
+    st_vox = None
+    # re-run the prefix for a slice through the C ABI to inspect the packed lists
+    n = 4096
+    ridx = torch.arange(100000, 100000 + n, dtype=torch.int32, device="cuda")
+    views = scene.view_indices_with_neighbors(0, 4)
+    P = ctx.dev(np.array([scene.get_image(v).camera.P for v in views], np.float32))
+    Pi = ctx.dev(scene.get_image(0).camera.P_pinv.astype(np.float32))
+    cc = ctx.dev(scene.get_image(0).camera.center.ravel().astype(np.float32))
+    vox = torch.zeros((n, M), dtype=torch.int32, device="cuda")
+    rvc = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    Sr = torch.zeros((n, M), device="cuda")
+    ctx.scene_prepare(ridx, [bank.view_features(scene, v) for v in views], P, Pi, cc, vox, rvc, Sr)
+    v = vox.cpu().numpy().astype(np.int64)
+    xyz = np.stack([v >> 20, (v >> 10) & 1023, v & 1023], -1)
+    cnt = rvc.cpu().numpy()
+    step = np.abs(np.diff(xyz, axis=1)).sum(-1)
+    valid = (np.arange(M - 1)[None, :] + 1) < cnt[:, None]
+    assert np.all(step[valid] == 1)
+    assert np.all((xyz[valid.nonzero()[0], valid.nonzero()[1]] < 128))
+    # resident columns are probability distributions
+    s = Sr.cpu().numpy()
+    has = cnt >= 1
+    assert np.abs(s.sum(1)[has] - 1).max() < 1e-4 and (s >= 0).all()
+    # determinism up to float-atomic ordering: a second run agrees closely
+    fp2 = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 130000)
+    depths2 = list(fp2.forward_pass(scene, (0, 2, 1)))
+    assert float((fp2.accumulator - acc).abs().max()) < 1e-2
+    assert (np.abs(depths2[0] - depths[0]) > 1e-4).mean() < 1e-3

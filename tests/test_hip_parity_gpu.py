@@ -1,0 +1,507 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the
+golden vectors generated from the reference.  Needs a real MI355X: `-m gpu`.
+
+Bar (north_star / SURVEY.md Q8): ray<->voxel index maps, ray end points and plane
+indices bit-exact; distributions <= 1e-5 abs; log-odds messages / accumulators
+within the fp32 conditioning bound; depth maps within 1e-4 except documented
+arg-max near-ties."""
+import numpy as np
+import pytest
+
+from conftest import load_cases
+
+pytestmark = pytest.mark.gpu
+
+CU = load_cases("crosscheck_cu_host.npz")
+TRAV = load_cases("ref_traversal.npz")
+MRF = load_cases("ref_mrf_np.npz")
+MAP = load_cases("ref_mapping_np.npz")
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no CPU fallback exists)"
+    from raynet_amd import _lib
+    _lib.build()
+    return torch
+
+
+def logit_tol(ref_msg):
+    return 1e-5 + 8 * 2.0 ** -24 * np.exp(np.minimum(np.abs(ref_msg), 17.0))
+
+
+def make_case(oracle_mod, c):
+    o = oracle_mod.Oracle(M=int(c["M"]), D=int(c["D"]), N=int(c["N"]), F=int(c["F"]),
+                          H=int(c["H"]), W=int(c["W"]), padding=int(c["padding"]),
+                          bbox=c["bbox"], grid_shape=c["grid"])
+    rng = np.random.default_rng(int(c["seed"]))
+    feats = rng.standard_normal((o.N, o.H + o.padding + 1, o.W + o.padding + 1, o.F),
+                                dtype=np.float32) * np.float32(0.25)
+    vg = oracle_mod.voxel_grid_centers(c["bbox"], c["grid"])
+    return o, feats, vg
+
+
+def hip_ctx(o):
+    from raynet_amd.hip_implementations import get_context
+    return get_context(o.M, o.D, o.N, o.F, o.H, o.W, o.padding, o.bbox, o.grid_shape)
+
+
+# ------------------------------------------------------------------ a1
+@pytest.mark.parametrize("case", sorted(CU))
+def test_sample_rays_bit_exact(torch, oracle_mod, case):
+    c = CU[case]
+    o, _, _ = make_case(oracle_mod, c)
+    ctx = hip_ctx(o)
+    ridx = ctx.dev(c["ray_idxs"])
+    n = len(ridx)
+    s = torch.zeros((n, 3), device="cuda")
+    e = torch.zeros((n, 3), device="cuda")
+    ctx.sample_rays(ridx, ctx.dev(c["P_inv"]), ctx.dev(c["center"]), s, e)
+    so, eo = o.sample(c["ray_idxs"], c["P_inv"], c["center"])
+    assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(e.cpu().numpy(), eo)
+    assert np.array_equal(so, c["starts"]) and np.array_equal(eo, c["ends"])
+
+
+def test_sample_points_k8(torch, oracle_mod):
+    """K8 (sample_points.py:12-54): D points per ray, homogeneous coordinate 1."""
+    from raynet_amd.hip_implementations.sample_points import batch_sample_points
+    c = CU["small"]
+    o, _, _ = make_case(oracle_mod, c)
+    sp = batch_sample_points(o.D, o.H, o.W, o.bbox, "sample_in_bbox")
+    pts = torch.zeros((len(c["ray_idxs"]), o.D, 4), device="cuda")
+    sp(c["ray_idxs"], c["P_inv"], c["center"], pts)
+    pts = pts.cpu().numpy()
+    s, e = c["starts"], c["ends"]
+    k = np.arange(o.D, dtype=np.float32)[None, :, None]
+    expect = s[:, None, :] + k * (e - s)[:, None, :] / np.float32(o.D - 1)
+    assert np.array_equal(pts[..., :3], expect.astype(np.float32))
+    assert np.all(pts[..., 3] == 1.0)
+
+
+# ------------------------------------------------------------------ a2
+@pytest.mark.parametrize("case", sorted(CU))
+@pytest.mark.parametrize("generic", [False, True])
+def test_similarities(torch, oracle_mod, case, generic, monkeypatch):
+    """K7.  The generic sweep walks the dot product in the reference's order (equal to
+    the oracle up to expf); the cooperative F=32 sweep re-associates the 32-term sums."""
+    c = CU[case]
+    o, feats, _ = make_case(oracle_mod, c)
+    if generic:
+        monkeypatch.setenv("RAYNET_HIP_GENERIC_SWEEP", "1")
+    ctx = hip_ctx(o)
+    n = len(c["ray_idxs"])
+    S = torch.zeros((n, o.D), device="cuda")
+    ctx.compute_similarities(ctx.dev(feats), ctx.dev(c["P"]), ctx.dev(c["starts"]),
+                             ctx.dev(c["ends"]), S)
+    So = o.similarities(feats, c["P"], c["starts"], c["ends"])
+    S = S.cpu().numpy()
+    assert np.abs(S.sum(1) - 1).max() < 1e-5
+    tol = 2e-6 if (generic or o.F != 32) else 1e-5
+    assert np.abs(S - So).max() <= tol
+    assert np.abs(S - c["S"]).max() <= tol
+
+
+# ------------------------------------------------------------------ a3
+@pytest.mark.parametrize("case", sorted(TRAV))
+def test_traversal_bit_exact_vs_reference_cython(torch, oracle_mod, case):
+    """K5 against index maps produced by the reference's compiled Cython traversal."""
+    from raynet_amd.ray_marching.ray_tracing_hip import batch_voxel_traversal
+    c = TRAV[case]
+    M = int(c["M"])
+    vtr = batch_voxel_traversal(M, c["bbox"], c["grid"])
+    n = len(c["starts"])
+    rvi = torch.zeros((n, M, 3), dtype=torch.int32, device="cuda")
+    rvc = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    vtr(c["starts"], c["ends"], rvi, rvc)
+    assert np.array_equal(rvc.cpu().numpy(), c["rvc"])          # 0 is written explicitly (Q11)
+    assert np.array_equal(rvi.cpu().numpy(), c["rvi"].astype(np.int32))
+
+
+def test_traversal_reference_unit_tests(torch):
+    """tests/test_ray_marching.py:20-102 run against the drop-in single-ray signature."""
+    from raynet_amd.ray_marching.ray_tracing_hip import voxel_traversal
+    bbox = np.array([3, 3, 0, 6, 6, 1], dtype=np.float32)
+    grid_shape = np.array([3, 3, 1], dtype=np.int32)
+    voxels = np.empty((10, 3), dtype=np.int32)
+    voxels.fill(0)
+    N = voxel_traversal(bbox, grid_shape, voxels, np.array([3., 4.1, 0.5], dtype=np.float32),
+                        np.array([6., 4.9, 0.5], dtype=np.float32))
+    assert N == 3
+    assert np.all(voxels[:3, 1] == 1) and np.all(voxels[:3, 0] == np.arange(3))
+    for s, e, cnt in [([4., 6., .5], [6., 5., .5], 2), ([3., 3., .5], [6., 6., .5], 5),
+                      ([6., 6., .5], [3., 3., .5], 5)]:
+        voxels.fill(0)
+        assert voxel_traversal(bbox, grid_shape, voxels, np.array(s, np.float32),
+                               np.array(e, np.float32)) == cnt
+    bbox = np.array([0, 0, 0, 6, 6, 1], dtype=np.float32)
+    grid_shape = np.array([6, 6, 1], dtype=np.int32)
+    rvi = np.zeros((10, 3), dtype=np.int32)
+    Nr = voxel_traversal(bbox, grid_shape, rvi, np.array([0., 3.5, 0.5], dtype=np.float32),
+                         np.array([6., 0.5, 0.5], dtype=np.float32))
+    assert Nr == 9
+    assert np.all(rvi == np.array([[0, 3, 0], [0, 2, 0], [1, 2, 0], [2, 2, 0], [2, 1, 0], [3, 1, 0],
+                                   [4, 1, 0], [4, 0, 0], [5, 0, 0], [0, 0, 0]]))
+    bbox = np.array([-3., -3., -0.5, 3., 3., 2.], dtype=np.float32)
+    grid_shape = np.array([32, 32, 10], dtype=np.int32)
+    voxels = np.zeros((100, 3), dtype=np.int32)
+    N = voxel_traversal(bbox, grid_shape, voxels,
+                        np.array([-1.40056884, -1.34645462, 2.], dtype=np.float32),
+                        np.array([-2.30040455, 3., -0.37297964], dtype=np.float32))
+    assert N < 50
+
+
+def test_traversal_large_random_vs_oracle(torch, oracle_mod):
+    """20k chords through 128^3 (M=384), including truncation at M, vs the oracle."""
+    from raynet_amd.ray_marching.ray_tracing_hip import batch_voxel_traversal
+    rng = np.random.default_rng(3)
+    bbox = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    grid = np.array([128, 128, 128], np.int32)
+    n = 20000
+    starts = (rng.random((n, 3)) * 2.4 - 1.2).astype(np.float32)
+    ends = (rng.random((n, 3)) * 2.4 - 1.2).astype(np.float32)
+    for M in (384, 64):
+        o = oracle_mod.Oracle(M=M, D=8, N=2, F=4, H=4, W=4, padding=3, bbox=bbox, grid_shape=grid)
+        vtr = batch_voxel_traversal(M, bbox, grid)
+        rvi = torch.zeros((n, M, 3), dtype=torch.int32, device="cuda")
+        rvc = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        vtr(starts, ends, rvi, rvc)
+        rvi_o, rvc_o = o.traversal(starts, ends)
+        assert np.array_equal(rvc.cpu().numpy(), rvc_o)
+        assert np.array_equal(rvi.cpu().numpy(), rvi_o)
+        if M == 64:
+            assert (rvc_o == M).any()       # silent truncation at M (ray_tracing.cu:100)
+
+
+# ------------------------------------------------------------------ a4
+@pytest.mark.parametrize("case", sorted(CU))
+def test_mapping_vs_oracle(torch, oracle_mod, case):
+    """K6 on real traversals: plane walk reproduced exactly, values to fp32 rounding."""
+    from raynet_amd.planes_voxels_mapping.planes_voxels_mapping_hip import \
+        batch_depth_to_voxels_mapping
+    c = CU[case]
+    o, feats, vg = make_case(oracle_mod, c)
+    pvm = batch_depth_to_voxels_mapping(o.M, o.D, o.grid_shape, o.bbox)
+    rvi = c["rvi"].astype(np.int32)
+    n = len(rvi)
+    out = torch.zeros((n, o.M), device="cuda")
+    pvm(vg, rvi, c["rvc"], c["starts"], c["ends"], c["S"], out)
+    out = out.cpu().numpy()
+    ref = o.planes_to_voxels(vg, rvi, c["rvc"], c["starts"], c["ends"], c["S"])
+    assert np.abs(out - ref).max() <= 2e-7
+    assert np.abs(out - c["S_voxel"]).max() <= 2e-7
+    for r in range(n):
+        assert np.all(out[r, c["rvc"][r]:] == 0)
+
+
+@pytest.mark.parametrize("case", sorted(MAP))
+def test_mapping_vs_reference_numpy(torch, case):
+    """K6 vs the reference's NumPy `li` / `li_2` (planes_voxels_mapping.py:122-211)."""
+    from raynet_amd.planes_voxels_mapping.planes_voxels_mapping_hip import \
+        batch_depth_to_voxels_mapping
+    c = MAP[case]
+    C, D = len(c["voxels"]), len(c["s"])
+    if D < 2:
+        pytest.skip("D=1 undefined")
+    M = C + 3
+    pvm = batch_depth_to_voxels_mapping(M, D, (C, 1, 1))
+    grid = np.zeros((C, 1, 1, 3), np.float32)
+    grid[:, 0, 0, :] = c["voxels"]
+    rvi = np.zeros((1, M, 3), np.int32)
+    rvi[0, :C, 0] = np.arange(C)
+    out = torch.zeros((1, M), device="cuda")
+    pvm(grid, rvi, np.array([C], np.int32), c["start"][None], c["end"][None], c["s"][None], out)
+    out = out.cpu().numpy()
+    assert np.allclose(out[0, :C], c["li"], rtol=2e-5, atol=1e-7)
+    assert np.allclose(out[0, :C], c["li_2"], rtol=2e-5, atol=1e-7)
+    assert np.all(out[0, C:] == 0)
+
+
+# ---------------------------------------------------------------- a5 / a6 / a9
+class _GP(object):
+    def __init__(self, grid_shape, M):
+        self.grid_shape = grid_shape
+        self.max_number_of_marched_voxels = M
+
+
+@pytest.mark.parametrize("case", sorted(MRF))
+def test_bp_backend_vs_reference_numpy(torch, oracle_mod, case):
+    """get_bp_backend("hip") through the reference's BPInference interface, against
+    outputs of mrf/mrf_np.py (accumulator, messages, depth distribution) and the oracle."""
+    from raynet_amd.mrf.bp_inference import get_bp_backend
+    c = MRF[case]
+    N, M = c["S"].shape
+    bp = get_bp_backend("hip", _GP(c["grid"], M), bp_iterations=3, batch_size=max(1, N // 2))
+    init = np.random.default_rng(0).random((N, M)).astype(np.float32)   # ignored, like the reference
+    acc, msgs = bp.update_bp_messages(c["S"], c["rvi"], c["rvc"], init)
+    prior = np.float32(np.log(0.05) - np.log(0.95))
+    assert np.all(np.abs(acc - c["accs"][-1]) <= logit_tol(c["accs"][-1] - prior) * 4)
+    assert np.all(np.abs(msgs - c["msgs"]) <= logit_tol(c["msgs"]))
+    S_new = bp.estimate_depth_probabilities_from_messages(
+        c["S"], c["rvi"], c["rvc"], acc, msgs, np.zeros_like(c["S"]))
+    assert np.abs(S_new - c["S_new"]).max() < 1e-5
+    skip = c["rvc"] <= 1
+    assert np.all(msgs[skip] == 0) and np.all(S_new[skip] == 0)
+    # and the fp32 oracle (same arithmetic up to scan association / expf / logf)
+    o = oracle_mod.Oracle(M=M, D=8, N=2, F=4, H=4, W=4, padding=3, bbox=(0, 0, 0, 1, 1, 1),
+                          grid_shape=c["grid"])
+    acc_o, msgs_o = o.belief_propagation(c["S"], c["rvi"], c["rvc"], np.zeros_like(c["S"]))
+    assert np.all(np.abs(msgs - msgs_o) <= logit_tol(msgs_o))
+
+
+def _occupancy(acc):
+    mx = np.maximum(0.0, acc)
+    t1, t2 = np.exp(0.0 - mx), np.exp(acc - mx)
+    return t2 / (t2 + t1)
+
+
+def test_bp_reference_property_tests(torch):
+    """tests/test_mrf.py (:73-76, :140-144, :213-215, :281-304, :349, :414-416) with the
+    HIP backend in place of numpy/tf/cuda."""
+    from raynet_amd.mrf.bp_inference import get_bp_backend
+    res = {}
+    for case in ("single_ray", "two_rays", "two_rays_2", "three_rays", "conflict"):
+        c = MRF[case]
+        N, M = c["S"].shape
+        bp = get_bp_backend("hip", _GP(c["grid"], M), bp_iterations=3, batch_size=N)
+        acc, msgs = bp.update_bp_messages(c["S"], c["rvi"], c["rvc"],
+                                          np.random.random((N, M)).astype(np.float32))
+        res[case] = (bp, c, acc, msgs, _occupancy(acc))
+    p = res["single_ray"][4]
+    ix = np.where(p == p.max())
+    assert ix[0][0] == 2 and ix[1][0] == 2
+    p = res["two_rays"][4].T
+    assert max(p[0, 4, 3], p[0, 2, 2]) >= p.max() - 1e-12
+    p = res["two_rays_2"][4].T
+    assert p[0, 2, 2] >= p.max() - 1e-12
+    p = res["three_rays"][4].T
+    order = np.sort(p[0].ravel())[::-1]
+    assert p[0, 2, 2] == order[0] and p[0, 2, 0] == order[1] and p[0, 4, 4] == order[2]
+    bp, c, acc, msgs, p = res["conflict"]
+    assert p.T[0, 0, 2] < 0.1
+    S_new = bp.estimate_depth_probabilities_from_messages(c["S"], c["rvi"], c["rvc"], acc, msgs,
+                                                          np.zeros_like(c["S"]))
+    assert S_new[0, 2] < 0.5 and S_new[0, 6] > 0.9 and S_new[1, 4] > 0.9
+
+
+def test_mrf_inference_and_errors(torch):
+    from raynet_amd.mrf.bp_inference import get_bp_backend
+    c = MRF["rand32"]
+    N, M = c["S"].shape
+    bp = get_bp_backend("hip", _GP(c["grid"], M), batch_size=N)
+    acc, msgs, S_new = bp.mrf_inference(c["S"], c["rvi"], c["rvc"], np.zeros_like(c["S"]),
+                                        np.zeros_like(c["S"]))
+    assert np.abs(S_new - c["S_new"]).max() < 1e-5
+    with pytest.raises(AssertionError):       # bp_inference.py:179-189
+        bp.update_bp_messages(c["S"].astype(np.float64), c["rvi"], c["rvc"], np.zeros_like(c["S"]))
+    with pytest.raises(AssertionError):
+        bp.update_bp_messages(c["S"], c["rvi"][:, :-1], c["rvc"], np.zeros_like(c["S"]))
+    with pytest.raises(NotImplementedError):
+        get_bp_backend("numpy", _GP(c["grid"], M))
+    with pytest.raises(ValueError):
+        get_bp_backend("hip", _GP(c["grid"], M))
+
+
+# ------------------------------------------------------------------ a7
+@pytest.mark.parametrize("case", sorted(CU))
+@pytest.mark.parametrize("generic", [False, True])
+def test_fused_k1_k2(torch, oracle_mod, case, generic, monkeypatch):
+    """perform_raynet_fp closures (K1, K2) vs the oracle's fused functions and vs the
+    reference's CUDA device functions executed on the host."""
+    from raynet_amd.hip_implementations.raynet_fp import perform_raynet_fp
+    if generic:
+        monkeypatch.setenv("RAYNET_HIP_GENERIC_SWEEP", "1")
+    c = CU[case]
+    o, feats, vg = make_case(oracle_mod, c)
+    fp, de = perform_raynet_fp(o.M, o.D, o.N, o.F, o.H, o.W, o.padding, o.bbox, o.grid_shape,
+                               "sample_in_bbox")
+    n = len(c["ray_idxs"])
+    dev = "cuda"
+    prior = o.prior(float(c["gamma"]))
+    acc_in = torch.from_numpy(prior).to(dev)
+    acc_out = torch.from_numpy(prior.copy()).to(dev)
+    msgs = torch.zeros((n, o.M), device=dev)
+    rvi = torch.zeros((n, o.M, 3), dtype=torch.int32, device=dev)
+    rvc = torch.zeros((n,), dtype=torch.int32, device=dev)
+    Sv = torch.zeros((n, o.M), device=dev)
+    vg_d = torch.from_numpy(vg).to(dev)
+    feats_d = torch.from_numpy(feats).to(dev)
+    ret = fp(c["ray_idxs"], feats_d, c["P"], c["P_inv"], c["center"], vg_d, rvi, rvc, Sv, acc_in,
+             msgs, acc_out)
+    assert ret is msgs
+    # oracle
+    acc_o = prior.copy()
+    msgs_o = np.zeros((n, o.M), np.float32)
+    rvi_o, rvc_o, Sv_o = o.fused_bp(c["ray_idxs"], feats, c["P"], c["P_inv"], c["center"], vg,
+                                    prior, msgs_o, acc_o)
+    assert np.array_equal(rvc.cpu().numpy(), rvc_o)
+    assert np.array_equal(rvi.cpu().numpy(), rvi_o)                    # bit-exact index maps
+    tolS = 2e-6 if (generic or o.F != 32) else 2e-5
+    assert np.abs(Sv.cpu().numpy() - Sv_o).max() <= tolS
+    m = msgs.cpu().numpy()
+    assert np.all(np.abs(m - msgs_o) <= logit_tol(msgs_o) * (1 if generic else 8))
+    assert np.all(np.abs(m - c["msgs"]) <= logit_tol(c["msgs"]) * (1 if generic else 8))
+    assert np.abs(acc_out.cpu().numpy() - acc_o).max() <= 2e-4
+    # K2 on the oracle's accumulator / messages (isolates K2)
+    depth = torch.zeros((n,), device=dev)
+    rvi.zero_(); rvc.zero_(); Sv.zero_()
+    de(c["ray_idxs"], feats_d, c["P"], c["P_inv"], c["center"], vg_d, rvi, rvc, Sv,
+       torch.from_numpy(acc_o).to(dev), torch.from_numpy(msgs_o).to(dev), depth)
+    _, _, S_new_o, depth_o = o.fused_depth(c["ray_idxs"], feats, c["P"], c["P_inv"], c["center"],
+                                           vg, acc_o, msgs_o)
+    S_new = Sv.cpu().numpy()      # K2 leaves the final distribution in S_voxel_space
+    assert np.abs(S_new - S_new_o).max() <= 1e-5
+    d = np.abs(depth.cpu().numpy() - depth_o)
+    flips = d > 1e-4
+    # a flip is legitimate only where the two best voxels are a near tie
+    for r in np.where(flips)[0]:
+        top = np.sort(S_new_o[r])[::-1]
+        assert top[0] - top[1] <= 2e-5, (r, top[:2])
+    assert flips.mean() <= 0.02
+
+
+@pytest.mark.parametrize("case", ["wide", "aniso"])
+def test_resident_scene_path_equals_fused(torch, oracle_mod, case):
+    """rn_scene_prepare / rn_scene_bp_sweep / rn_scene_depth (packed voxel lists, resident
+    clipped columns, per-copy accumulators) give what K1 / K2 give."""
+    c = CU[case]
+    o, feats, vg = make_case(oracle_mod, c)
+    ctx = hip_ctx(o)
+    dev = "cuda"
+    ctx.set_voxel_grid(torch.from_numpy(vg).to(dev))
+    n = len(c["ray_idxs"])
+    ridx = ctx.dev(c["ray_idxs"])
+    feats_d = torch.from_numpy(feats).to(dev)
+    P, Pi, cc = ctx.dev(c["P"]), ctx.dev(c["P_inv"]), ctx.dev(c["center"])
+    vox = torch.zeros((n, o.M), dtype=torch.int32, device=dev)
+    rvc = torch.zeros((n,), dtype=torch.int32, device=dev)
+    Sr = torch.zeros((n, o.M), device=dev)
+    ctx.scene_prepare(ridx, [feats_d[v] for v in range(o.N)], P, Pi, cc, vox, rvc, Sr)
+    rvi = c["rvi"].astype(np.int32)
+    packed = (rvi[..., 0] << 20) | (rvi[..., 1] << 10) | rvi[..., 2]
+    vox_h, rvc_h = vox.cpu().numpy(), rvc.cpu().numpy()
+    assert np.array_equal(rvc_h, c["rvc"])
+    for r in range(n):
+        assert np.array_equal(vox_h[r, :rvc_h[r]], packed[r, :rvc_h[r]])
+    prior_v = float(np.float32(np.log(0.05) - np.log(0.95)))
+    G = tuple(o.grid_shape)
+    acc_in = torch.full(G, prior_v, device=dev)
+    part = torch.zeros((ctx.acc_copies(),) + G, device=dev)
+    acc_next = torch.empty(G, device=dev)
+    msgs = torch.zeros((n, o.M), device=dev)
+    acc_o = o.prior(0.05)
+    msgs_o = np.zeros((n, o.M), np.float32)
+    for it in range(3):
+        ctx.scene_bp_sweep(Sr, vox, rvc, acc_in, msgs, part)
+        ctx.acc_combine(part, prior_v, acc_next)
+        acc_in, acc_next = acc_next, acc_in
+        assert float(part.abs().max()) == 0.0          # copies are re-zeroed
+        out = o.prior(0.05)
+        o.fused_bp(c["ray_idxs"], feats, c["P"], c["P_inv"], c["center"], vg, acc_o, msgs_o, out)
+        acc_o = out
+    assert np.all(np.abs(msgs.cpu().numpy() - msgs_o) <= logit_tol(msgs_o) * 8)
+    assert np.abs(acc_in.cpu().numpy() - acc_o).max() <= 5e-4
+    S_new = torch.zeros((n, o.M), device=dev)
+    depth = torch.zeros((n,), device=dev)
+    ctx.scene_depth(Sr, vox, rvc, torch.from_numpy(acc_o).to(dev), torch.from_numpy(msgs_o).to(dev),
+                    cc, S_new, depth)
+    _, _, S_new_o, depth_o = o.fused_depth(c["ray_idxs"], feats, c["P"], c["P_inv"], c["center"],
+                                           vg, acc_o, msgs_o)
+    assert np.abs(S_new.cpu().numpy() - S_new_o).max() <= 1e-5
+    assert (np.abs(depth.cpu().numpy() - depth_o) > 1e-4).mean() <= 0.02
+
+
+def test_mvcnn_kernels_k9_to_k12(torch, oracle_mod):
+    from raynet_amd.hip_implementations.similarities import \
+        perform_multi_view_cnn_forward_pass, \
+        perform_multi_view_cnn_forward_pass_with_depth_estimation
+    from raynet_amd.hip_implementations.mvcnn_with_ray_marching_and_voxels_mapping import \
+        batch_mvcnn_voxel_traversal_with_ray_marching, \
+        batch_mvcnn_voxel_traversal_with_ray_marching_with_depth_estimation
+    c = CU["wide"]
+    o, feats, vg = make_case(oracle_mod, c)
+    n = len(c["ray_idxs"])
+    args = (o.D, o.N, o.F, o.H, o.W, o.padding, o.bbox, "sample_in_bbox")
+    S = torch.zeros((n, o.D), device="cuda")
+    perform_multi_view_cnn_forward_pass(*args)(c["ray_idxs"], feats, c["P"], c["P_inv"],
+                                               c["center"], S)
+    assert np.abs(S.cpu().numpy() - c["S"]).max() <= 1e-5
+    S2 = torch.zeros((n, o.D), device="cuda")
+    pts = torch.zeros((n, o.D, 4), device="cuda")
+    depth = torch.zeros((n,), device="cuda")
+    perform_multi_view_cnn_forward_pass_with_depth_estimation(*args)(
+        c["ray_idxs"], feats, c["P"], c["P_inv"], c["center"], S2, pts, depth)
+    k = np.argmax(c["S"], axis=1)                       # similarities.py:199-227
+    p = pts.cpu().numpy()[np.arange(n), k, :3]
+    expect = np.sqrt(((p - c["center"][:3]) ** 2).sum(1))
+    near_tie = np.sort(c["S"], axis=1)[:, -1] - np.sort(c["S"], axis=1)[:, -2] < 1e-5
+    assert np.abs(depth.cpu().numpy() - expect)[~near_tie].max() <= 1e-5
+    vargs = (o.M, o.D, o.N, o.F, o.H, o.W, o.padding, o.bbox, o.grid_shape, "sample_in_bbox")
+    rvi = torch.zeros((n, o.M, 3), dtype=torch.int32, device="cuda")
+    rvc = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    Sv = torch.zeros((n, o.M), device="cuda")
+    batch_mvcnn_voxel_traversal_with_ray_marching(*vargs)(
+        c["ray_idxs"], feats, c["P"], c["P_inv"], c["center"], vg, rvi, rvc, Sv)
+    assert np.array_equal(rvi.cpu().numpy(), c["rvi"].astype(np.int32))
+    assert np.abs(Sv.cpu().numpy() - c["S_voxel"]).max() <= 2e-5
+    d12 = torch.zeros((n,), device="cuda")
+    batch_mvcnn_voxel_traversal_with_ray_marching_with_depth_estimation(*vargs)(
+        c["ray_idxs"], feats, c["P"], c["P_inv"], c["center"], vg, rvi, rvc, Sv, d12)
+    Svh = c["S_voxel"]
+    i = np.argmax(Svh, axis=1)
+    cen = vg[tuple(c["rvi"][np.arange(n), i].astype(np.int64).T)]
+    expect = np.sqrt(((cen - c["center"][:3]) ** 2).sum(1))
+    srt = np.sort(Svh, axis=1)
+    near_tie = srt[:, -1] - srt[:, -2] < 1e-5
+    assert np.abs(d12.cpu().numpy() - expect)[~near_tie].max() <= 1e-5
+
+
+# ----------------------------------------------------------------- edges
+def test_empty_and_state_errors(torch, oracle_mod):
+    from raynet_amd import _lib
+    from raynet_amd.hip_implementations.context import HipContext
+    ctx = HipContext(32, 8, 2, 4, 8, 8, 3, (0, 0, 0, 1, 1, 1), (4, 4, 4))
+    z = torch.zeros((0, 3), device="cuda")
+    ctx.voxel_traversal(z, z, torch.zeros((0, 32, 3), dtype=torch.int32, device="cuda"),
+                        torch.zeros((0,), dtype=torch.int32, device="cuda"))       # n = 0 is fine
+    with pytest.raises(_lib.RaynetHipError, match="RN_ERR_STATE"):
+        ctx.planes_to_voxels(torch.zeros((1, 32, 3), dtype=torch.int32, device="cuda"),
+                             torch.zeros((1,), dtype=torch.int32, device="cuda"),
+                             torch.zeros((1, 3), device="cuda"), torch.zeros((1, 3), device="cuda"),
+                             torch.zeros((1, 8), device="cuda"), torch.zeros((1, 32), device="cuda"))
+    with pytest.raises(_lib.RaynetHipError):
+        HipContext(32, 8, 2, 4, 8, 8, 3, (0, 0, 0, 1, 1, 1), (4, 4, 4000))      # grid too large
+    from raynet_amd.ray_marching.ray_marching import get_voxel_traversal_backend
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    with pytest.raises(NotImplementedError):
+        get_voxel_traversal_backend("cython")
+    with pytest.raises(KeyError):
+        get_forward_pass_factory("hartmann_fp")
+
+
+def test_rays_missing_the_box(torch, oracle_mod):
+    """Rays that never enter the grid: count 0, no message, depth = distance to voxel
+    (0,0,0) as in the reference's zero-filled buffers."""
+    from raynet_amd.hip_implementations.raynet_fp import perform_raynet_fp
+    c = CU["small"]
+    o, feats, vg = make_case(oracle_mod, c)
+    o2 = oracle_mod.Oracle(M=o.M, D=o.D, N=o.N, F=o.F, H=o.H, W=o.W, padding=o.padding,
+                           bbox=(5, 5, 5, 6, 6, 6), grid_shape=o.grid_shape)
+    vg2 = oracle_mod.voxel_grid_centers(o2.bbox, o2.grid_shape)
+    fp, de = perform_raynet_fp(o.M, o.D, o.N, o.F, o.H, o.W, o.padding, o2.bbox, o2.grid_shape,
+                               "sample_in_bbox")
+    n = 64
+    ridx = c["ray_idxs"][:n]
+    prior = o2.prior(0.05)
+    acc_out = torch.from_numpy(prior.copy()).cuda()
+    msgs = torch.zeros((n, o.M), device="cuda")
+    rvi = torch.zeros((n, o.M, 3), dtype=torch.int32, device="cuda")
+    rvc = torch.full((n,), 5, dtype=torch.int32, device="cuda")
+    Sv = torch.zeros((n, o.M), device="cuda")
+    fp(ridx, feats, c["P"], c["P_inv"], c["center"], vg2, rvi, rvc, Sv, prior, msgs, acc_out)
+    assert int(rvc.abs().sum()) == 0 and float(msgs.abs().sum()) == 0.0
+    assert np.array_equal(acc_out.cpu().numpy(), prior)
+    depth = torch.zeros((n,), device="cuda")
+    de(ridx, feats, c["P"], c["P_inv"], c["center"], vg2, rvi, rvc, Sv, prior, msgs, depth)
+    expect = np.sqrt(((vg2[0, 0, 0] - c["center"][:3]) ** 2).sum())
+    assert np.allclose(depth.cpu().numpy(), expect, rtol=1e-6)
