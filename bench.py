@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: rays/sec through RayNet's forward_pass hot path
+at 5 views x 64 depth planes x 128^3 voxels, on N MI355X of one node.
+
+One "step" = one complete pass of the hot path over the synthetic scene
+(SURVEY.md 8d): for each of the V=5 reference images (480x640 rays each) the K1
+prefix (ray sampling, plane sweep + softmax, voxel traversal, planes->voxels
+mapping), then 3 BP sweeps over all images with the accumulator hand-over after each
+(plus one RCCL all-reduce per iteration when N>1), then the depth sweep, through the
+public RayNetForwardPass.forward_pass generator (depth maps are copied back to the
+host like the reference's `.get()`).  Feature maps are resident in HBM when the timed
+region starts (the MV-CNN is outside the path); nothing is cached between steps.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus 8 --steps 5 --warmup 1
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     dominant kernel family: algorithmic bytes of its
+               launches in the timed region / their hipEvent durations (per launch, on
+               the launch stream, via rn_prof_begin/rn_prof_end), vs the 8 TB/s HBM peak
+  cpu_baseline the C oracle's fused K1/K2 path (a port of the reference's algorithm,
+               OpenMP over rays) on a bounded ray sample of the same scene, on this
+               box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+CONFIGS = {
+    # BASELINE.json configs[1] / [2]: the configuration the metric is quoted on
+    "config2": dict(H=480, W=640, views=5, D=64, M=384, grid=(128, 128, 128), F=32, padding=11,
+                    workload="synthetic 5-view scene, 480x640 rays/view, 64 depth planes, "
+                             "128^3 voxels, M=384, 3 BP iterations + depth sweep"),
+    # BASELINE.json configs[3] (DTU-style), for reference runs
+    "config4": dict(H=480, W=640, views=9, D=128, M=768, grid=(256, 256, 256), F=32, padding=11,
+                    workload="synthetic 9-view scene, 640x480, 128 depth planes, 256^3 voxels"),
+    "small": dict(H=120, W=160, views=5, D=64, M=384, grid=(128, 128, 128), F=32, padding=11,
+                  workload="reduced 120x160 (debug only)"),
+}
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(kernel, n_rays, voxels, cfg):
+    """Algorithmic HBM bytes of ONE launch.  voxels = sum of the
+    per-ray voxel counts of the rays in the launch."""
+    N, F = cfg["views"], cfg["F"]
+    Hf, Wf = cfg["H"] + cfg["padding"] + 1, cfg["W"] + cfg["padding"] + 1
+    if kernel == "traverse":      # write packed voxel list + count, read ray index
+        return 4 * voxels + 8 * n_rays
+    if kernel == "sweep_map":     # N feature maps once; read voxel list, write column
+        return 4 * N * F * Hf * Wf + 8 * voxels + 8 * n_rays
+    if kernel == "bp":            # Sr, voxel list, msg in, acc gather, msg out
+        return 20 * voxels + 4 * n_rays
+    if kernel == "scatter":       # msg, voxel list, atomic RMW of the accumulator (8)
+        return 16 * voxels + 4 * n_rays
+    if kernel == "depth":         # Sr, voxel list, msg, acc gather; depth out
+        return 16 * voxels + 8 * n_rays
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="config2", choices=sorted(CONFIGS))
+    ap.add_argument("--schedule", default="resident", choices=["resident", "reference"])
+    ap.add_argument("--rays-batch", type=int, default=0, help="0 = one launch per image shard")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raynet_amd import _lib
+    from raynet_amd.common.generation_parameters import GenerationParameters
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    _lib.load()     # fails loudly if the HIP library was not built
+
+    cfg = CONFIGS[args.config]
+    H, W, V = cfg["H"], cfg["W"], cfg["views"]
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=V, F=cfg["F"], padding=cfg["padding"],
+                                       focal=1.5 * H, seed=1234)
+    gp = GenerationParameters(depth_planes=cfg["D"], neighbors=min(4, V - 1) if V <= 5 else V - 1,
+                              grid_shape=np.array(cfg["grid"], np.int32),
+                              max_number_of_marched_voxels=cfg["M"], padding=cfg["padding"],
+                              gamma_mrf=0.05)
+    cfg["views_per_ray"] = gp.neighbors + 1
+    fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W),
+                                            args.rays_batch, schedule=args.schedule)
+    images_range = (0, V, 1)
+
+    def step():
+        out = None
+        for out in fp.forward_pass(scene, images_range):
+            pass
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx = fp._ctx
+    fence()
+    ctx.prof_begin(capacity=64 * V * max(args.steps, 1) + 64)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches = ctx.prof_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    rays_per_step = V * H * W
+    value = rays_per_step * args.steps / elapsed
+
+    # ---- per-kernel accounting (this rank's launches) ------------------------------
+    counts = {r: fp.voxel_count[r] for r in fp.voxel_count}
+    vox_by_n = {}
+    for r, c in counts.items():
+        vox_by_n.setdefault(int(c.numel()), []).append(float(c.sum().item()))
+    mean_vox = float(sum(float(c.sum().item()) for c in counts.values()) /
+                     max(1, sum(int(c.numel()) for c in counts.values())))
+    fam = {}
+    cfg_acc = dict(cfg, views=gp.neighbors + 1)
+    for name, n_rays, ms in launches:
+        f = fam.setdefault(name, dict(ms=0.0, launches=0, bytes=0.0))
+        f["ms"] += ms
+        f["launches"] += 1
+        if n_rays:
+            # launches are per image shard: voxels of a launch = mean over images with n rays
+            vs = vox_by_n.get(n_rays)
+            vox = float(np.mean(vs)) if vs else mean_vox * n_rays
+            f["bytes"] += algorithmic_bytes(name, n_rays, vox, cfg_acc)
+    dominant = max((k for k in fam if k != "acc"), key=lambda k: fam[k]["ms"], default=None)
+    roofline = None
+    if dominant:
+        d = fam[dominant]
+        achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dominant)
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 1),
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                        traffic=traffic,
+                        avg_launch_ms=round(d["ms"] / d["launches"], 4), launches=d["launches"],
+                        algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]))
+    kernels = {k: dict(total_ms_per_step=round(v["ms"] / args.steps, 3),
+                       launches_per_step=v["launches"] / args.steps,
+                       algorithmic_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+                       if v["ms"] > 0 and v["bytes"] else None)
+               for k, v in sorted(fam.items())}
+
+    # ---- CPU baseline: the oracle's fused path on a bounded ray sample ----------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        threads = oracle.Oracle.max_threads()
+        o = oracle.Oracle(M=cfg["M"], D=cfg["D"], N=gp.neighbors + 1, F=cfg["F"], H=H, W=W,
+                          padding=cfg["padding"], bbox=scene.bbox.ravel(), grid_shape=cfg["grid"],
+                          threads=threads)
+        vg = oracle.voxel_grid_centers(scene.bbox.ravel(), cfg["grid"])
+        views = scene.view_indices_with_neighbors(0, gp.neighbors)
+        feats = bank.stacked(views).cpu().numpy()
+        P = np.array([scene.get_image(v).camera.P for v in views], np.float32)
+        Pi = scene.get_image(0).camera.P_pinv.astype(np.float32)
+        cc = scene.get_image(0).camera.center.ravel().astype(np.float32)
+        rng = np.random.default_rng(0)
+
+        def cpu_run(n):
+            ridx = np.sort(rng.choice(H * W, n, replace=False)).astype(np.int32)
+            acc = o.prior(0.05)
+            msgs = np.zeros((n, cfg["M"]), np.float32)
+            t = time.perf_counter()
+            for it in range(3):                      # forward_pass.py:593-678
+                out = o.prior(0.05)
+                o.fused_bp(ridx, feats, P, Pi, cc, vg, acc, msgs, out)
+                acc = out
+            o.fused_depth(ridx, feats, P, Pi, cc, vg, acc, msgs)      # :682-736
+            return time.perf_counter() - t
+
+        probe = min(2000, H * W)
+        tp = cpu_run(probe)
+        n = int(min(H * W, max(probe, probe * args.cpu_seconds / max(tp, 1e-6))))
+        tc = cpu_run(n)
+        cpu = dict(value=round(n / tc, 1), unit="rays/s", cores=threads, kind="port",
+                   sample="%d rays of reference image 0 (of %d per step), 3 BP sweeps + depth "
+                          "sweep with the oracle's fused K1/K2 (oracle/raynet_oracle.c, OpenMP), "
+                          "%.1f s" % (n, rays_per_step, tc))
+
+    if rank == 0:
+        result = {
+            "metric": "rays/sec (whole node) at 5 views x 64 depths x 128^3 voxels",
+            "value": round(value, 1),
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": cfg["workload"], "name": args.config,
+                       "rays_per_step": rays_per_step, "bp_iterations": 3,
+                       "schedule": args.schedule,
+                       "parallelism": "rays sharded x%d, 1 all-reduce/BP iteration" % world
+                       if world > 1 else "single GPU",
+                       "mean_voxels_per_ray": round(mean_vox, 2)},
+            "ray_sweeps_per_s": round(4 * value, 1),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+        }
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

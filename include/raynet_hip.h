@@ -209,7 +209,8 @@ typedef enum {
     RN_K_BP = 3,         /* BP sweep                                         */
     RN_K_DEPTH = 4,      /* depth estimation / arg-max                       */
     RN_K_ACC = 5,        /* accumulator combine / fill                       */
-    RN_K_OTHER = 6
+    RN_K_OTHER = 6,
+    RN_K_SCATTER = 7     /* accumulator scatter of the BP messages (tile-transposed) */
 } rn_kernel_id;
 int rn_prof_begin(rn_ctx *ctx, int32_t capacity);
 int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *n_rays_host,

@@ -252,7 +252,10 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
 //   CLIP_IN: S is the raw voxel-space column (API mode) and is clipped +
 //            renormalised here; otherwise it is the resident Sr.
 //   acc_out may be one of several per-XCD copies (xcd_stride != 0).
-template <int NCH, bool PACKED, bool CLIP_IN, bool XCD_LOCAL>
+//   SCATTER: add the messages to acc_out with one atomic per voxel from this kernel
+//            (lanes = consecutive voxels of ONE ray: 64 different cache lines per
+//            instruction).  The drivers use SCATTER=false + k_scatter_tile instead.
+template <int NCH, bool PACKED, bool CLIP_IN, bool XCD_LOCAL, bool SCATTER>
 __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
                                               const int32_t *__restrict__ vox,
                                               const int32_t *__restrict__ rvc,
@@ -322,7 +325,24 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
             wv[ch] = w;
         }
     }
-    const float W = carryC;   // cumsum1 of mrf_bp.cu:115-133
+    // (cumsum1 - cumsum2) of mrf_bp.cu:157 is the suffix sum  sum_{j>i} w_j.  The reference
+    // forms it as a difference of two running sums, which is exact-or-zero only because
+    // both are the SAME sequential sum; with wave scans that difference could go negative
+    // by an ulp (log of a negative number -> NaN), so the suffix is scanned directly.  It
+    // is non-negative by construction and free of the reference's cancellation.
+    float suf[NCH];
+    {
+        float carryS = 0.0f;
+#pragma unroll
+        for (int ch = NCH - 1; ch >= 0; ch--) {
+            suf[ch] = 0.0f;
+            if (ch * WAVE < count) {
+                float tot;
+                suf[ch] = carryS + wave_suffix_excl(wv[ch], lane, tot);
+                carryS = carryS + tot;
+            }
+        }
+    }
 
     // pass B: messages (mrf_bp.cu:136-167) and scatter (:170-176)
 #pragma unroll
@@ -330,12 +350,12 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
         if (ch * WAVE < count) {
             const int i = ch * WAVE + lane;
             if (i < count) {
-                const float cin = cex[ch] + wv[ch];
                 float pos = cex[ch] + tsv[ch];
-                const float neg = cex[ch] + (W - cin) / (1.0f - ov[ch]);
+                const float neg = cex[ch] + suf[ch] / (1.0f - ov[ch]);
                 pos = pos / (pos + neg);
                 const float m = logf(pos) - logf(1.0f - pos);
                 mout_row[i] = m;
+                if (!SCATTER) continue;
                 if (XCD_LOCAL)   // copy private to this XCD: its own L2 is the coherence point
                     __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -344,6 +364,223 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
                                            __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    }
+}
+
+// ------------------------------------------------- accumulator scatter, transposed
+// mrf_bp.cu:170-176 (acc_out[voxel] += message) for a tile of 64 CONSECUTIVE rays.
+// A float atomic costs one L2 request per distinct cache line of the instruction
+// (measured: 21 G scattered vs 324 G coalesced atomics/s, tools/atomic_bench.hip).  With
+// lanes = voxels of one ray every lane hits its own line.  Here the [64 rays][64 steps]
+// message / voxel tiles go through LDS and are read back transposed, so one instruction
+// carries step s of 64 neighbouring rays: neighbouring pixels of an image column pierce
+// the same or vertically adjacent voxels, i.e. consecutive floats of the z-fastest grid.
+constexpr int TILE_PAD = 65;
+template <bool PACKED>
+__global__ __launch_bounds__(BLOCK) void k_scatter_tile(Params p, int n,
+                                                        const float *__restrict__ msgs,
+                                                        const int32_t *__restrict__ vox,
+                                                        const int32_t *__restrict__ rvc,
+                                                        float *acc_out, int64_t xcd_stride) {
+    __shared__ float tile_m[WAVE * TILE_PAD];
+    __shared__ int32_t tile_v[WAVE * TILE_PAD];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = threadIdx.x >> 6;
+    const int r0 = xcd_block(blockIdx.x, gridDim.x) * WAVE;
+    if (xcd_stride) {
+        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
+        acc_out += xcc * xcd_stride;
+    }
+    // lane = ray of the tile
+    int cnt = 0;
+    if (r0 + lane < n) {
+        cnt = min(rvc[r0 + lane], p.M);
+        if (cnt <= 1) cnt = 0;        // such rays send no message (mrf_np.py:300)
+    }
+    int maxc = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+    maxc = uniform(maxc);
+    constexpr int ROWS = WAVE / WAVES_PER_BLOCK;      // rows (and steps) per wave: 16
+    for (int base = 0; base < maxc; base += WAVE) {
+        // coalesced row loads: wave `wid` brings in rays wid*16 .. wid*16+15
+#pragma unroll 4
+        for (int j = 0; j < ROWS; j++) {
+            const int row = wid * ROWS + j;
+            const int c = __shfl(cnt, row);
+            float m = 0.0f;
+            int32_t v = 0;
+            if (base + lane < c) {
+                const size_t off = (size_t)(r0 + row) * p.M + base + lane;
+                m = msgs[off];
+                if (PACKED) {
+                    v = vox[off];
+                } else {
+                    const int32_t *t = vox + off * 3;
+                    v = pack_voxel(t[0], t[1], t[2]);
+                }
+            }
+            tile_m[row * TILE_PAD + lane] = m;
+            tile_v[row * TILE_PAD + lane] = v;
+        }
+        __syncthreads();
+        // transposed: this wave scatters steps wid*16 .. wid*16+15 of all 64 rays
+#pragma unroll 4
+        for (int j = 0; j < ROWS; j++) {
+            const int s = wid * ROWS + j;
+            if (base + s < cnt) {
+                const float m = tile_m[lane * TILE_PAD + s];
+                const int32_t v = tile_v[lane * TILE_PAD + s];
+                const int lin = ((v >> 20) * p.gy + ((v >> 10) & 1023)) * p.gz + (v & 1023);
+                __hip_atomic_fetch_add(acc_out + lin, m, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------- accumulator scatter, slab-ordered
+// Same job as k_scatter_tile, but the atomics of a 64-ray tile are issued in order of
+// the voxels' coordinate along the tile's dominant travel axis instead of in step order.
+// The 64 rays of a tile are neighbouring pixels of one image column: they lie in one
+// plane through the camera, so inside one slab of the dominant axis their voxels share
+// (nearly) the same column of the grid and differ along z -- consecutive floats.  One
+// instruction then touches a handful of cache lines instead of 64 (an L2 float atomic
+// costs one request per line: 21 G/s scattered vs 324 G/s coalesced, tools/atomic_bench.hip).
+// Any ray order is CORRECT (every element is emitted exactly once; the flush loop takes
+// what an unexpected ordering left behind); coherence only buys speed.
+constexpr int SLAB_STEPS = 32;
+constexpr int SLAB_PAD = SLAB_STEPS + 1;
+template <bool PACKED>
+__global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
+                                                       const float *__restrict__ msgs,
+                                                       const int32_t *__restrict__ vox,
+                                                       const int32_t *__restrict__ rvc,
+                                                       float *acc_out, int64_t xcd_stride) {
+    __shared__ float tile_m[WAVE * SLAB_PAD];
+    __shared__ int32_t tile_v[WAVE * SLAB_PAD];
+    const int lane = threadIdx.x;
+    const int r0 = xcd_block(blockIdx.x, gridDim.x) * WAVE;
+    if (xcd_stride) {
+        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
+        acc_out += xcc * xcd_stride;
+    }
+    int cnt = 0;
+    if (r0 + lane < n) {
+        cnt = min(rvc[r0 + lane], p.M);
+        if (cnt <= 1) cnt = 0;        // such rays send no message (mrf_np.py:300)
+    }
+    int maxc = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+    maxc = uniform(maxc);
+    if (maxc == 0) return;
+
+    // dominant axis / direction of the tile: sum over rays of (last voxel - first voxel)
+    int shift = 0, flip = 0;
+    {
+        int dx = 0, dy = 0, dz = 0;
+        if (cnt > 0) {
+            int x0, y0, z0, x1, y1, z1;
+            const int32_t *row = vox + (size_t)(r0 + lane) * p.M * (PACKED ? 1 : 3);
+            load_voxel<PACKED>(row, 0, x0, y0, z0);
+            load_voxel<PACKED>(row, cnt - 1, x1, y1, z1);
+            dx = x1 - x0; dy = y1 - y0; dz = z1 - z0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            dx += __shfl_xor(dx, o);
+            dy += __shfl_xor(dy, o);
+            dz += __shfl_xor(dz, o);
+        }
+        const int ax = abs(dx), ay = abs(dy), az = abs(dz);
+        if (ax >= ay && ax >= az) { shift = 20; flip = dx < 0; }
+        else if (ay >= az) { shift = 10; flip = dy < 0; }
+        else { shift = 0; flip = dz < 0; }
+        shift = uniform(shift);
+        flip = uniform(flip);
+    }
+    auto key_of = [&](int32_t v) {
+        const int c = (v >> shift) & 1023;
+        return flip ? 1023 - c : c;
+    };
+
+    for (int base = 0; base < maxc; base += SLAB_STEPS) {
+        // rows in: two rays per instruction, 32 steps (128 B) each
+#pragma unroll 4
+        for (int j = 0; j < WAVE; j += 2) {
+            const int row = j + (lane >> 5);
+            const int col = lane & 31;
+            const int c = __shfl(cnt, row);
+            float m = 0.0f;
+            int32_t v = 0;
+            if (base + col < c) {
+                const size_t off = (size_t)(r0 + row) * p.M + base + col;
+                m = msgs[off];
+                if (PACKED) {
+                    v = vox[off];
+                } else {
+                    const int32_t *t = vox + off * 3;
+                    v = pack_voxel(t[0], t[1], t[2]);
+                }
+            }
+            tile_m[row * SLAB_PAD + col] = m;
+            tile_v[row * SLAB_PAD + col] = v;
+        }
+        wave_sync();
+
+        const int nvalid = min(max(cnt - base, 0), SLAB_STEPS);
+        int cursor = 0;
+        int32_t vcur = nvalid > 0 ? tile_v[lane * SLAB_PAD] : 0;
+        // slab range of this chunk (first / last element of every ray; exact when the
+        // rays move monotonically along the tile's axis, which is the normal case)
+        int kmin = nvalid > 0 ? key_of(vcur) : 1 << 30;
+        int kmax = nvalid > 0 ? key_of(tile_v[lane * SLAB_PAD + nvalid - 1]) : -1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            kmin = min(kmin, __shfl_xor(kmin, o));
+            kmax = max(kmax, __shfl_xor(kmax, o));
+        }
+        kmin = uniform(kmin);
+        kmax = uniform(kmax);
+        for (int k = kmin; k <= kmax + 1; k++) {
+            const int limit = (k > kmax) ? (1 << 30) : k;     // last round flushes everything
+            while (true) {
+                const bool emit = cursor < nvalid && key_of(vcur) <= limit;
+                if (__ballot(emit) == 0) break;
+                // Neighbouring rays usually sit in the SAME voxel (ray spacing < voxel size);
+                // an instruction with duplicate addresses is serialised by the L2 (x6 for
+                // pairs, tools/atomic_bench2.hip).  Runs of equal addresses in adjacent lanes
+                // are therefore summed first (segmented scan inside rows of 16 lanes) and only
+                // the last lane of each run issues the atomic.
+                float val = 0.0f;
+                int lin = -2 - lane;                 // unique: a non-emitting lane is its own run
+                if (emit) {
+                    val = tile_m[lane * SLAB_PAD + cursor];
+                    lin = ((vcur >> 20) * p.gy + ((vcur >> 10) & 1023)) * p.gz + (vcur & 1023);
+                }
+                int head = dpp_i<0x111, 0xf>(0x7fffffff, lin) != lin;     // row start: head
+#define RN_SEG_STEP(CTRL)                                             \
+    {                                                                 \
+        const float vp = dpp_f<CTRL, 0xf>(0.0f, val);                 \
+        const int fp = dpp_i<CTRL, 0xf>(1, head);                     \
+        if (!head) val += vp;                                         \
+        head |= fp;                                                   \
+    }
+                RN_SEG_STEP(0x111) RN_SEG_STEP(0x112) RN_SEG_STEP(0x114) RN_SEG_STEP(0x118)
+#undef RN_SEG_STEP
+                const bool tail = dpp_i<0x101, 0xf>(0x7ffffffe, lin) != lin;   // row_shl:1
+                if (emit) {
+                    if (tail)
+                        __hip_atomic_fetch_add(acc_out + lin, val, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    cursor++;
+                    if (cursor < nvalid) vcur = tile_v[lane * SLAB_PAD + cursor];
+                }
+            }
+        }
+        wave_sync();
     }
 }
 
@@ -506,8 +743,9 @@ struct rn_ctx {
     float *axes;          // device, gx+gy+gz
     bool have_axes;
     int copies;           // accumulator copies used by the resident path
-    int acc_mode;         // 0: one copy, agent-scope atomics; 1: one copy per XCD, agent scope;
-                          // 2: one copy per XCD, atomics resolved in that XCD's L2
+    int acc_mode;         // 0: one accumulator copy; 1: one copy per XCD (A/B knob)
+    bool fused_scatter;   // scatter from inside k_bp instead of a scatter kernel (A/B knob)
+    int scatter_mode;     // 0: slab-ordered (default), 1: step-ordered tile (A/B knob)
     hipEvent_t ev0, ev1;
     // per-launch profiling (rn_prof_begin / rn_prof_end)
     bool prof_on;
@@ -620,24 +858,44 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
     launch_sweep_t<1, 1, 8, MAPMODE, PACKED>(ctx, a, st);
 }
 
-template <bool PACKED, bool CLIP_IN, bool XCD_LOCAL>
+template <bool PACKED, bool CLIP_IN>
 int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
               const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
               int64_t xcd_stride, hipStream_t st) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
-    ProfScope prof(ctx, RN_K_BP, n, st);
-#define RN_BP(NCH_)                                                                       \
-    hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, XCD_LOCAL>), dim3(ray_blocks(n)),     \
-                       dim3(BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, acc_out, \
-                       msgs_out, xcd_stride)
-    if (nch <= 2) RN_BP(2);
-    else if (nch <= 4) RN_BP(4);
-    else if (nch <= 6) RN_BP(6);
-    else if (nch <= 8) RN_BP(8);
-    else if (nch <= 12) RN_BP(12);
-    else RN_BP(16);
+    const bool fused = ctx->fused_scatter;
+    {
+        ProfScope prof(ctx, RN_K_BP, n, st);
+#define RN_BP(NCH_)                                                                         \
+    do {                                                                                    \
+        if (fused)                                                                          \
+            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, false, true>), dim3(ray_blocks(n)), \
+                               dim3(BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in,  \
+                               acc_out, msgs_out, xcd_stride);                               \
+        else                                                                                \
+            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, false, false>),                   \
+                               dim3(ray_blocks(n)), dim3(BLOCK), 0, st, ctx->p, n, Sv, vox,   \
+                               rvc, acc_in, msgs_in, acc_out, msgs_out, xcd_stride);         \
+    } while (0)
+        if (nch <= 2) RN_BP(2);
+        else if (nch <= 4) RN_BP(4);
+        else if (nch <= 6) RN_BP(6);
+        else if (nch <= 8) RN_BP(8);
+        else if (nch <= 12) RN_BP(12);
+        else RN_BP(16);
 #undef RN_BP
+    }
     RN_LAUNCH_CHECK(ctx);
+    if (!fused) {
+        ProfScope prof(ctx, RN_K_SCATTER, n, st);
+        if (ctx->scatter_mode == 1)
+            hipLaunchKernelGGL((k_scatter_tile<PACKED>), dim3((n + WAVE - 1) / WAVE), dim3(BLOCK),
+                               0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, xcd_stride);
+        else
+            hipLaunchKernelGGL((k_scatter_slab<PACKED>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE),
+                               0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, xcd_stride);
+        RN_LAUNCH_CHECK(ctx);
+    }
     return RN_OK;
 }
 
@@ -698,10 +956,13 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     p.Hf = cfg->H + cfg->padding + 1;
     p.Wf = cfg->W + cfg->padding + 1;
     for (int i = 0; i < 6; i++) p.bbox[i] = cfg->bbox[i];
-    // RAYNET_HIP_ACC_MODE picks how rn_scene_bp_sweep scatters (see rn_ctx::acc_mode)
+    // RAYNET_HIP_ACC_MODE / RAYNET_HIP_FUSED_SCATTER: measurement knobs, see rn_ctx
     const char *am = getenv("RAYNET_HIP_ACC_MODE");
     ctx->acc_mode = am ? atoi(am) : 0;
-    if (ctx->acc_mode < 0 || ctx->acc_mode > 2) ctx->acc_mode = 0;
+    if (ctx->acc_mode < 0 || ctx->acc_mode > 1) ctx->acc_mode = 0;
+    ctx->fused_scatter = getenv("RAYNET_HIP_FUSED_SCATTER") != nullptr;
+    const char *sm = getenv("RAYNET_HIP_SCATTER_MODE");
+    ctx->scatter_mode = sm ? atoi(sm) : 0;
     ctx->copies = ctx->acc_mode == 0 ? 1 : NXCD;
     if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
@@ -761,6 +1022,7 @@ int rn_fill_i32(rn_ctx *ctx, int32_t *dst, int64_t count, int32_t value, void *s
 
 int rn_sample_rays(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *P_inv,
                    const float *camera_center, float *ray_start, float *ray_end, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !P_inv || !camera_center || !ray_start || !ray_end)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
@@ -772,6 +1034,7 @@ int rn_sample_rays(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float 
 
 int rn_sample_points(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *P_inv,
                      const float *camera_center, float *points, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !P_inv || !camera_center || !points)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
@@ -784,6 +1047,7 @@ int rn_sample_points(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const floa
 int rn_compute_similarities(rn_ctx *ctx, int32_t n, const float *features, const float *P,
                             const float *ray_start, const float *ray_end, float *Sp,
                             void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !features || !P || !ray_start || !ray_end || !Sp)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
@@ -796,6 +1060,7 @@ int rn_compute_similarities(rn_ctx *ctx, int32_t n, const float *features, const
 
 int rn_voxel_traversal(rn_ctx *ctx, int32_t n, const float *ray_start, const float *ray_end,
                        int32_t *rvi, int32_t *rvc, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_start || !ray_end || !rvi || !rvc)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
@@ -812,6 +1077,7 @@ int rn_voxel_traversal(rn_ctx *ctx, int32_t n, const float *ray_start, const flo
 int rn_planes_to_voxels(rn_ctx *ctx, int32_t n, const int32_t *rvi, const int32_t *rvc,
                         const float *ray_start, const float *ray_end, const float *Sp,
                         float *S_new, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !rvi || !rvc || !ray_start || !ray_end || !Sp || !S_new)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     int rc = need_axes(ctx);
@@ -827,16 +1093,18 @@ int rn_planes_to_voxels(rn_ctx *ctx, int32_t n, const int32_t *rvi, const int32_
 int rn_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sv, const int32_t *rvi, const int32_t *rvc,
                 const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
                 void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !Sv || !rvi || !rvc || !acc_in || !msgs_in || !acc_out || !msgs_out)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
-    return launch_bp<false, true, false>(ctx, n, Sv, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
+    return launch_bp<false, true>(ctx, n, Sv, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
                                   S(stream));
 }
 
 int rn_depth_estimation(rn_ctx *ctx, int32_t n, const float *Sv, const int32_t *rvi,
                         const int32_t *rvc, const float *acc, const float *msgs, float *S_new,
                         void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !Sv || !rvi || !rvc || !acc || !msgs || !S_new)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
@@ -847,6 +1115,7 @@ int rn_depth_estimation(rn_ctx *ctx, int32_t n, const float *Sv, const int32_t *
 int rn_mvcnn_similarities(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
                           const float *P, const float *P_inv, const float *camera_center,
                           float *Sp, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !Sp)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
@@ -860,6 +1129,7 @@ int rn_mvcnn_similarities(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const
 int rn_mvcnn_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
                    const float *P, const float *P_inv, const float *camera_center, float *Sp,
                    float *points, float *depth_map, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !Sp ||
         !points || !depth_map)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -892,6 +1162,7 @@ static int prefix_api(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const flo
 int rn_mvcnn_voxel_space(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float *features,
                          const float *P, const float *P_inv, const float *camera_center,
                          int32_t *rvi, int32_t *rvc, float *S_voxel, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !rvi ||
         !rvc || !S_voxel)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -921,6 +1192,7 @@ int rn_fused_bp_sweep(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const flo
                       const float *P, const float *P_inv, const float *camera_center,
                       int32_t *rvi, int32_t *rvc, float *S_voxel, const float *acc_in,
                       const float *msgs_in, float *acc_out, float *msgs_out, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !rvi ||
         !rvc || !S_voxel || !acc_in || !msgs_in || !acc_out || !msgs_out)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -930,7 +1202,7 @@ int rn_fused_bp_sweep(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const flo
     rc = prefix_api(ctx, n, ray_idxs, features, P, P_inv, camera_center, rvi, rvc, S_voxel,
                     S(stream));
     if (rc) return rc;
-    return launch_bp<false, true, false>(ctx, n, S_voxel, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
+    return launch_bp<false, true>(ctx, n, S_voxel, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
                                   S(stream));
 }
 
@@ -938,6 +1210,7 @@ int rn_fused_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float 
                    const float *P, const float *P_inv, const float *camera_center, int32_t *rvi,
                    int32_t *rvc, float *S_voxel, const float *acc, const float *msgs,
                    float *depth_map, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !features || !P || !P_inv || !camera_center || !rvi ||
         !rvc || !S_voxel || !acc || !msgs || !depth_map)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -959,6 +1232,7 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
                      const float *const *features_views_host, const float *P, const float *P_inv,
                      const float *camera_center, int32_t *vox, int32_t *rvc, float *Sr,
                      void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !features_views_host || !P || !P_inv || !camera_center ||
         !vox || !rvc || !Sr)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -986,15 +1260,13 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
 int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                       const int32_t *rvc, const float *acc_in, float *msgs, float *acc_part,
                       void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc_in || !msgs || !acc_part)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
     const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
-    if (ctx->acc_mode == 2)
-        return launch_bp<true, false, true>(ctx, n, Sr, vox, rvc, acc_in, msgs, acc_part, msgs, G,
-                                            S(stream));
-    return launch_bp<true, false, false>(ctx, n, Sr, vox, rvc, acc_in, msgs, acc_part, msgs,
-                                         ctx->acc_mode == 1 ? G : 0, S(stream));
+    return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, msgs, acc_part, msgs,
+                                  ctx->acc_mode == 1 ? G : 0, S(stream));
 }
 
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream) {
@@ -1029,6 +1301,7 @@ int rn_acc_add_prior(rn_ctx *ctx, float *acc, float prior, void *stream) {
 int rn_scene_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                    const int32_t *rvc, const float *acc, const float *msgs,
                    const float *camera_center, float *S_new, float *depth_map, void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc || !msgs || (!S_new && !depth_map) ||
         (depth_map && !camera_center))
         return fail(ctx, RN_ERR_INVALID, "bad argument");

@@ -76,6 +76,15 @@ __device__ __forceinline__ int wave_scan_max(int x) {
 __device__ __forceinline__ float wave_shift1(float x, float first) {
     return dpp_f<0x138, 0xf>(first, x);
 }
+// suffix[i] = sum_{j>i} x[j] within the wavefront (exclusive reverse scan); also returns
+// the wave total through `total`
+__device__ __forceinline__ float wave_suffix_excl(float x, int lane, float &total) {
+    const float y = __shfl(x, 63 - lane);          // reverse lane order
+    const float incl = wave_scan_add(y);
+    total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
+    const float excl = dpp_f<0x138, 0xf>(0.0f, incl);
+    return __shfl(excl, 63 - lane);
+}
 __device__ __forceinline__ float lane63(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }

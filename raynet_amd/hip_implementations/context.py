@@ -105,7 +105,7 @@ class HipContext(object):
         self._check(self.lib.rn_timer_stop(self._h, _stream(), ctypes.byref(ms)))
         return float(ms.value)
 
-    KERNEL_NAMES = {1: "traverse", 2: "sweep_map", 3: "bp", 4: "depth", 5: "acc", 6: "other"}
+    KERNEL_NAMES = {1: "traverse", 2: "sweep_map", 3: "bp", 4: "depth", 5: "acc", 6: "other", 7: "scatter"}
 
     def prof_begin(self, capacity=4096):
         self._prof_cap = capacity

@@ -2,10 +2,12 @@
 
 N pinhole cameras on a ring around the bounding box look at the origin.  Instead
 of images + a trained MV-CNN (the reference ships no weights), each view gets a
-feature map with a *planted surface*: the feature at a pixel is a smooth function
-of the 3-D point its ray hits on a sphere (or on a background shell), plus noise.
-The same surface point therefore has the same feature in every view that sees it,
-so the plane-sweep similarity has a true peak and BP has something to converge to.
+feature map with *planted surfaces*: the feature at a pixel is a smooth function of
+the 3-D point its ray first hits on a sphere or on a ground disc (both inside the
+bounding box and visible from every camera), plus noise; rays that hit nothing carry
+noise only.  The same surface point therefore has the same feature in every view
+that sees it, so the plane-sweep similarity has a true peak and BP has something to
+converge to, while nothing outside the box pretends to be a surface.
 """
 import numpy as np
 import torch
@@ -47,8 +49,9 @@ def ring_cameras(n_views, H, W, radius=3.0, focal=None, arc=2 * np.pi, heights=N
     return cams
 
 
-def planted_feature_maps(cameras, H, W, F=32, padding=11, seed=1234, sphere_radius=0.6,
-                         shell_radius=4.0, noise=0.25, device="cuda"):
+def planted_feature_maps(cameras, H, W, F=32, padding=11, seed=1234, sphere_radius=0.5,
+                         sphere_center=(0.0, 0.0, -0.1), ground_z=-0.7, ground_radius=0.95,
+                         noise=0.25, device="cuda"):
     """One [H+p+1, W+p+1, F] float32 map per camera."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     freq = (torch.randn((3, F), generator=g) * 2.5).to(device)
@@ -58,6 +61,7 @@ def planted_feature_maps(cameras, H, W, F=32, padding=11, seed=1234, sphere_radi
     fy, fx = torch.meshgrid(torch.arange(Hf, device=device, dtype=torch.float64),
                             torch.arange(Wf, device=device, dtype=torch.float64), indexing="ij")
     pix = torch.stack([fx - off, fy - off, torch.ones_like(fx)], dim=-1)      # (Hf, Wf, 3)
+    sc = torch.tensor(sphere_center, dtype=torch.float64, device=device)
     maps = []
     for k, cam in enumerate(cameras):
         Kinv = torch.tensor(np.linalg.inv(cam.K), dtype=torch.float64, device=device)
@@ -65,21 +69,21 @@ def planted_feature_maps(cameras, H, W, F=32, padding=11, seed=1234, sphere_radi
         o = torch.tensor(np.asarray(cam.center, np.float64).ravel()[:3], device=device)
         d = (pix @ Kinv.T) @ Rt.T
         d = d / d.norm(dim=-1, keepdim=True)
-        b = (d * o).sum(-1)
-
-        def hit(radius, far):
-            c = (o * o).sum() - radius * radius
-            disc = b * b - c
-            ok = disc > 0
-            sq = torch.sqrt(torch.clamp(disc, min=0))
-            t = (-b + sq) if far else (-b - sq)
-            return ok & (t > 0), t
-
-        ok_s, t_s = hit(sphere_radius, False)
-        _, t_b = hit(shell_radius, True)
-        t = torch.where(ok_s, t_s, t_b)
-        X = (o + t[..., None] * d).to(torch.float32)
-        f = torch.cos(X @ freq + phase)
+        # sphere
+        oc = o - sc
+        b = (d * oc).sum(-1)
+        disc = b * b - ((oc * oc).sum() - sphere_radius ** 2)
+        t_s = -b - torch.sqrt(torch.clamp(disc, min=0))
+        hit_s = (disc > 0) & (t_s > 0)
+        # ground disc z = ground_z, seen from above
+        t_g = (ground_z - o[2]) / d[..., 2]
+        Xg = o + t_g[..., None] * d
+        hit_g = (d[..., 2] < 0) & (t_g > 0) & ((Xg[..., 0] ** 2 + Xg[..., 1] ** 2) < ground_radius ** 2)
+        inf = torch.full_like(t_s, float("inf"))
+        t = torch.minimum(torch.where(hit_s, t_s, inf), torch.where(hit_g, t_g, inf))
+        hit = torch.isfinite(t)
+        X = (o + torch.where(hit, t, torch.zeros_like(t))[..., None] * d).to(torch.float32)
+        f = torch.cos(X @ freq + phase) * hit[..., None].to(torch.float32)
         gk = torch.Generator(device="cpu").manual_seed(seed + 1000 + k)
         n = torch.randn((Hf, Wf, F), generator=gk).to(device)
         maps.append((f + noise * n).to(torch.float32).contiguous())

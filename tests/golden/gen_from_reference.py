@@ -250,7 +250,9 @@ def gen_mrf(ray_tracing, mrf_np, out):
 def gen_mapping(pvm, out):
     """NumPy `li` (np.interp) and `li_2` variants on voxels whose projections are
     non-decreasing along the ray (what a traversal produces and what the .cu
-    walk assumes, planes_voxels_mapping.cu:68-76)."""
+    walk assumes, planes_voxels_mapping.cu:68-76).  The centres lie on one line of
+    a separable grid so that the same case can be fed to the HIP path, which keeps
+    per-axis centre tables."""
     rng = np.random.default_rng(77)
     flat = {}
     for case, (C, D) in enumerate([(10, 5), (10, 5), (40, 32), (213, 64), (3, 2), (1, 16)]):
@@ -258,9 +260,12 @@ def gen_mapping(pvm, out):
         end = (rng.random(3) + 1).astype(np.float32)
         ray = end - start
         t = np.sort(rng.random(C)) * 1.2 - 0.1          # some beyond [0,1] -> clipped
-        lateral = np.cross(ray, rng.random(3))
-        voxels = start[None] + t[:, None] * ray[None] + 0.01 * rng.standard_normal((C, 1)) * lateral
-        voxels = voxels.astype(np.float32)
+        # voxel centres on a separable grid line (x_i, y0, z0), like a real voxel grid:
+        # the projection grows with x because ray_x > 0
+        y0, z0 = rng.random(2) * 0.2
+        rn = float((ray.astype(np.float64) ** 2).sum())
+        x = start[0] + (t * rn - ray[1] * (y0 - start[1]) - ray[2] * (z0 - start[2])) / ray[0]
+        voxels = np.stack([x, np.full(C, y0), np.full(C, z0)], axis=1).astype(np.float32)
         points = (start[:, None] + np.linspace(0, 1, D)[None] * ray[:, None])
         s = rng.random(D)
         s /= s.sum()

@@ -249,6 +249,92 @@ def test_bp_backend_vs_reference_numpy(torch, oracle_mod, case):
     assert np.all(np.abs(msgs - msgs_o) <= logit_tol(msgs_o))
 
 
+def _bp_truth_f64(S, rvi, rvc, acc, msgs):
+    """One BP sweep in float64 on the same fp32 inputs: the value
+    both fp32 implementations approximate.  Returns messages and, per entry, the
+    amplification of an ulp-of-W error in the reference's (cumsum1 - cumsum2)."""
+    out = np.zeros(msgs.shape, np.float64)
+    cancel = np.zeros(msgs.shape, np.float64)
+    lo, hi = np.float32(1e-5), np.float32(1 - 1e-5)
+    for r in range(len(rvc)):
+        c = int(rvc[r])
+        if c <= 1:
+            continue
+        s = np.clip(S[r, :c], lo, hi).astype(np.float64)
+        s /= s.sum()
+        idx = tuple(rvi[r, :c].T)
+        mu = acc[idx].astype(np.float64) - msgs[r, :c]
+        o = np.clip(1.0 / (1.0 + np.exp(-mu)), np.float32(1e-4), np.float32(1 - 1e-4))
+        T = np.concatenate([[1.0], np.cumprod(1 - o)[:-1]])
+        w = o * T * s
+        C = np.concatenate([[0.0], np.cumsum(w)[:-1]])
+        suf = np.cumsum(w[::-1])[::-1] - w
+        pos = C + T * s
+        neg = C + suf / (1 - o)
+        out[r, :c] = np.log(pos) - np.log(neg)
+        cancel[r, :c] = w.sum() / ((1 - o) * neg)
+    return out, cancel
+
+
+def test_bp_single_sweep_against_float64_truth(torch, oracle_mod):
+    """Saturated regime (|accumulator| up to 40 log-odds, peaked columns): the HIP sweep
+    stays within fp32 rounding x logit conditioning of the float64 value, and never
+    produces a non-finite message.  The oracle (reference arithmetic) is held to the
+    same bound plus the cancellation term of its (cumsum1 - cumsum2), mrf_bp.cu:157."""
+    from raynet_amd.mrf.mrf_hip import batch_ray_belief_propagation
+    rng = np.random.default_rng(42)
+    grid, M, n = (32, 32, 32), 96, 400
+    bbox = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    o = oracle_mod.Oracle(M=M, D=8, N=2, F=4, H=4, W=4, padding=3, bbox=bbox, grid_shape=grid)
+    starts = (rng.random((n, 3)) * 2 - 1).astype(np.float32)
+    ends = (rng.random((n, 3)) * 2 - 1).astype(np.float32)
+    axis = rng.integers(0, 3, n)
+    starts[np.arange(n), axis] = -1
+    ends[np.arange(n), axis] = 1
+    rvi, rvc = o.traversal(starts, ends)
+    S = np.zeros((n, M), np.float32)
+    for r in range(n):
+        c = rvc[r]
+        v = rng.random(c) ** 6 + 1e-6
+        v[rng.integers(0, c)] += rng.random() * 5
+        S[r, :c] = v / v.sum()
+    acc = (rng.random(grid) * 80 - 40).astype(np.float32)
+    msgs_in = (rng.random((n, M)) * 6 - 3).astype(np.float32)
+    truth, cancel = _bp_truth_f64(S, rvi, rvc, acc, msgs_in)
+    valid = np.arange(M)[None, :] < rvc[:, None]
+    eps = 2.0 ** -24
+    cond = 2 + np.exp(np.minimum(np.abs(truth), 30))
+    bp, _ = batch_ray_belief_propagation(M, grid)
+    m_hip = torch.from_numpy(msgs_in.copy()).cuda()
+    acc_out = torch.zeros(grid, device="cuda")
+    bp(S, rvi, rvc, acc, m_hip, acc_out)
+    m_hip = m_hip.cpu().numpy()
+    assert np.isfinite(m_hip).all()
+    # (1 - o) carries a relative error eps/(1-o) <= 6e-4 once o saturates at its clamp
+    tol_hip = 1e-3 + 32 * eps * cond
+    ratio = np.where(valid, np.abs(m_hip - truth) / tol_hip, 0)
+    wr, wi = np.unravel_index(ratio.argmax(), ratio.shape)
+    m_dbg = msgs_in.copy()
+    o.bp_sweep(S, rvi, rvc, acc, m_dbg, np.zeros(grid, np.float32))
+    assert ratio.max() <= 1, "ray %d (count %d) idx %d: hip %g truth %g oracle %g ratio %g; n_bad %d" % (
+        wr, rvc[wr], wi, m_hip[wr, wi], truth[wr, wi], m_dbg[wr, wi], ratio.max(), (ratio > 1).sum())
+    # scatter-add of exactly these messages
+    ref_acc = np.zeros(grid, np.float64)
+    for r in range(n):
+        np.add.at(ref_acc, tuple(rvi[r, :rvc[r]].T), m_hip[r, :rvc[r]].astype(np.float64))
+    assert np.abs(acc_out.cpu().numpy() - ref_acc).max() <= 1e-3
+    # the reference arithmetic on the same inputs
+    m_o = msgs_in.copy()
+    o.bp_sweep(S, rvi, rvc, acc, m_o, np.zeros(grid, np.float32))
+    fin = np.isfinite(m_o) & valid
+    tol_o = 1e-3 + 32 * eps * cond + 8 * eps * cancel
+    assert np.all(np.abs(m_o - truth)[fin] <= tol_o[fin])
+    # where the reference is well conditioned the two fp32 paths agree closely
+    easy = fin & (cancel < 1e3) & (np.abs(truth) < 8)
+    assert easy.sum() > 0.3 * valid.sum()
+    assert np.abs(m_hip - m_o)[easy].max() <= 2e-3
+
+
 def _occupancy(acc):
     mx = np.maximum(0.0, acc)
     t1, t2 = np.exp(0.0 - mx), np.exp(acc - mx)
