@@ -174,11 +174,15 @@ int rn_fused_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float 
  *   vox  [n][M] i32  packed (x<<20 | y<<10 | z)
  *   Sr   [n][M] f32  clip_and_renorm(S_voxel) (mrf_bp.cu:103-111)
  * features_views: N device pointers (HOST array), one [Hf][Wf][F] map per view,
- * so a bank of per-view feature maps needs no re-stacking per reference image. */
+ * so a bank of per-view feature maps needs no re-stacking per reference image.
+ * order (optional, may be NULL): a permutation of 0..n-1; wavefront i of the plane
+ * sweep works on ray order[i].  It changes nothing but the schedule: walking the
+ * rays along the direction of the epipolar lines keeps the neighbour views'
+ * feature rows in L2. */
 int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
                      const float *const *features_views_host, const float *P,
-                     const float *P_inv, const float *camera_center, int32_t *vox,
-                     int32_t *rvc, float *Sr, void *stream);
+                     const float *P_inv, const float *camera_center, const int32_t *order,
+                     int32_t *vox, int32_t *rvc, float *Sr, void *stream);
 
 /* acc_part: [rn_acc_copies()][gx][gy][gz] f32, zero before the first sweep of an
  * iteration; messages are scattered into one copy per XCD. */

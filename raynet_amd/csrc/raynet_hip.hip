@@ -151,7 +151,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
     const float *__restrict__ starts, const float *__restrict__ ends,
     const float *__restrict__ S_in, const float *__restrict__ axes_g,
     const int32_t *__restrict__ vox, const int32_t *__restrict__ rvc, float *S_planes,
-    float *S_voxel, float *depth_from_planes, float *points) {
+    float *S_voxel, float *depth_from_planes, float *points,
+    const int32_t *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int naxes = p.gx + p.gy + p.gz;
     float *axes = smem;
@@ -163,8 +164,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
         __syncthreads();
     }
     int lane;
-    const int r = ray_of_wave(n, lane);
+    int r = ray_of_wave(n, lane);
     if (r < 0) return;
+    if (order) r = uniform(order[r]);      // schedule only: which ray this wavefront takes
 
     float s[3], e[3];
     if (ray_idxs) {
@@ -450,6 +452,9 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_tile(Params p, int n,
 // costs one request per line: 21 G/s scattered vs 324 G/s coalesced, tools/atomic_bench.hip).
 // Any ray order is CORRECT (every element is emitted exactly once; the flush loop takes
 // what an unexpected ordering left behind); coherence only buys speed.
+#ifdef RN_SCATTER_STATS
+__device__ unsigned long long g_scatter_stats[8];   // rounds, emitting lanes, tails, 64B segments, chunks
+#endif
 constexpr int SLAB_STEPS = 32;
 constexpr int SLAB_PAD = SLAB_STEPS + 1;
 template <bool PACKED>
@@ -507,28 +512,59 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
     };
 
     for (int base = 0; base < maxc; base += SLAB_STEPS) {
-        // rows in: two rays per instruction, 32 steps (128 B) each
-#pragma unroll 4
-        for (int j = 0; j < WAVE; j += 2) {
-            const int row = j + (lane >> 5);
-            const int col = lane & 31;
-            const int c = __shfl(cnt, row);
-            float m = 0.0f;
-            int32_t v = 0;
-            if (base + col < c) {
-                const size_t off = (size_t)(r0 + row) * p.M + base + col;
-                m = msgs[off];
-                if (PACKED) {
-                    v = vox[off];
-                } else {
-                    const int32_t *t = vox + off * 3;
-                    v = pack_voxel(t[0], t[1], t[2]);
+        if (PACKED && (p.M % SLAB_STEPS) == 0) {
+            // rows in: 8 rays per instruction, each lane 4 consecutive steps (16 B); all 16
+            // loads of the chunk are in flight before the first LDS write
+            const int sub = lane >> 3, q = lane & 7;
+            float4 mv[8];
+            int4 vv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int row = 8 * j + sub;
+                const int c = __shfl(cnt, row);      // all lanes take part in the shuffle
+                mv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vv[j] = make_int4(0, 0, 0, 0);
+                if (r0 + row < n && base < c) {
+                    const size_t off = (size_t)(r0 + row) * p.M + base + 4 * q;
+                    mv[j] = *reinterpret_cast<const float4 *>(msgs + off);
+                    vv[j] = *reinterpret_cast<const int4 *>(vox + off);
                 }
             }
-            tile_m[row * SLAB_PAD + col] = m;
-            tile_v[row * SLAB_PAD + col] = v;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int a = (8 * j + sub) * SLAB_PAD + 4 * q;
+                tile_m[a] = mv[j].x; tile_m[a + 1] = mv[j].y;
+                tile_m[a + 2] = mv[j].z; tile_m[a + 3] = mv[j].w;
+                tile_v[a] = vv[j].x; tile_v[a + 1] = vv[j].y;
+                tile_v[a + 2] = vv[j].z; tile_v[a + 3] = vv[j].w;
+            }
+        } else {
+            // generic layout: two rays per instruction, 32 steps each
+#pragma unroll 4
+            for (int j = 0; j < WAVE; j += 2) {
+                const int row = j + (lane >> 5);
+                const int col = lane & 31;
+                const int c = __shfl(cnt, row);
+                float m = 0.0f;
+                int32_t v = 0;
+                if (base + col < c) {
+                    const size_t off = (size_t)(r0 + row) * p.M + base + col;
+                    m = msgs[off];
+                    if (PACKED) {
+                        v = vox[off];
+                    } else {
+                        const int32_t *t = vox + off * 3;
+                        v = pack_voxel(t[0], t[1], t[2]);
+                    }
+                }
+                tile_m[row * SLAB_PAD + col] = m;
+                tile_v[row * SLAB_PAD + col] = v;
+            }
         }
         wave_sync();
+#ifdef RN_SCATTER_STATS
+        if (lane == 0) atomicAdd(&g_scatter_stats[4], 1ull);
+#endif
 
         const int nvalid = min(max(cnt - base, 0), SLAB_STEPS);
         int cursor = 0;
@@ -571,6 +607,29 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
                 RN_SEG_STEP(0x111) RN_SEG_STEP(0x112) RN_SEG_STEP(0x114) RN_SEG_STEP(0x118)
 #undef RN_SEG_STEP
                 const bool tail = dpp_i<0x101, 0xf>(0x7ffffffe, lin) != lin;   // row_shl:1
+#ifdef RN_SCATTER_STATS
+                {
+                    const bool t = emit && tail;
+                    const unsigned long long bt = __ballot(t);
+                    // distinct 64-byte segments among the issuing lanes (exact count)
+                    int seg = t ? (lin >> 4) : -1;
+                    int distinct = 0;
+                    unsigned long long left = bt;
+                    while (left) {
+                        const int l = __builtin_ctzll(left);
+                        const int sv = __shfl(seg, l);
+                        const unsigned long long same = __ballot(t && seg == sv);
+                        left &= ~same;
+                        distinct++;
+                    }
+                    if (lane == 0) {
+                        atomicAdd(&g_scatter_stats[0], 1ull);
+                        atomicAdd(&g_scatter_stats[1], (unsigned long long)__builtin_popcountll(__ballot(emit)));
+                        atomicAdd(&g_scatter_stats[2], (unsigned long long)__builtin_popcountll(bt));
+                        atomicAdd(&g_scatter_stats[3], (unsigned long long)distinct);
+                    }
+                }
+#endif
                 if (emit) {
                     if (tail)
                         __hip_atomic_fetch_add(acc_out + lin, val, __ATOMIC_RELAXED,
@@ -825,6 +884,7 @@ struct SweepArgs {
     const float *P, *P_inv, *cc, *starts, *ends, *S_in;
     const int32_t *vox, *rvc;
     float *S_planes, *S_voxel, *depth_from_planes, *points;
+    const int32_t *order = nullptr;
 };
 
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
@@ -833,7 +893,7 @@ void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
     hipLaunchKernelGGL((k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>), dim3(ray_blocks(a.n)),
                        dim3(BLOCK), sweep_lds(ctx->p), st, ctx->p, a.n, a.ray_idxs, a.fv, a.P,
                        a.P_inv, a.cc, a.starts, a.ends, a.S_in, ctx->axes, a.vox, a.rvc,
-                       a.S_planes, a.S_voxel, a.depth_from_planes, a.points);
+                       a.S_planes, a.S_voxel, a.depth_from_planes, a.points, a.order);
 }
 
 // pick the plane-sweep flavour: cooperative for F=32 and 2..9 views, generic otherwise
@@ -1230,8 +1290,8 @@ int rn_acc_copies(const rn_ctx *ctx) { return ctx ? ctx->copies : 0; }
 
 int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
                      const float *const *features_views_host, const float *P, const float *P_inv,
-                     const float *camera_center, int32_t *vox, int32_t *rvc, float *Sr,
-                     void *stream) {
+                     const float *camera_center, const int32_t *order, int32_t *vox, int32_t *rvc,
+                     float *Sr, void *stream) {
     if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !features_views_host || !P || !P_inv || !camera_center ||
         !vox || !rvc || !Sr)
@@ -1252,6 +1312,7 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
     RN_LAUNCH_CHECK(ctx);
     SweepArgs a{n, ray_idxs, fv, P, P_inv, camera_center, nullptr, nullptr, nullptr, vox, rvc,
                 nullptr, Sr, nullptr, nullptr};
+    a.order = order;
     launch_sweep<2, true>(ctx, a, true, S(stream));
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
@@ -1347,6 +1408,21 @@ int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *
     *count = n;
     return RN_OK;
 }
+
+#ifdef RN_SCATTER_STATS
+int rn_debug_scatter_stats(unsigned long long *out_host, int reset) {
+    if (out_host &&
+        hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_scatter_stats), sizeof(unsigned long long) * 8) !=
+            hipSuccess)
+        return RN_ERR_HIP;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scatter_stats), z, sizeof(z)) != hipSuccess)
+            return RN_ERR_HIP;
+    }
+    return RN_OK;
+}
+#endif
 
 int rn_timer_start(rn_ctx *ctx, void *stream) {
     if (!ctx) return RN_ERR_INVALID;

@@ -30,6 +30,8 @@ sharded contiguously over the ranks; each rank scatters into its own zeroed
 accumulator and one all-reduce (RCCL) per BP iteration merges them before the
 prior is added once.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -46,6 +48,33 @@ def _dist():
     if dist.is_available() and dist.is_initialized():
         return dist, dist.get_rank(), dist.get_world_size()
     return None, 0, 1
+
+
+def sweep_order(ray_idxs, H, W, images):
+    """Schedule of the plane sweep: the order in which the wavefronts take the rays.
+
+    A ray reads the feature vectors along its epipolar line in every neighbour view.
+    Rays whose pixels lie ALONG an epipolar line share those lines, so walking the
+    image in that direction keeps a few feature rows per view hot in the XCD's L2
+    instead of streaming the whole map for every image column.  Returns an int32
+    permutation (CUDA tensor) or None for the natural (column-major) order."""
+    ref = images[0].camera
+    P = np.asarray(ref.P, np.float64)
+    dx = dy = 0.0
+    for im in images[1:]:
+        e = P.dot(np.asarray(im.camera.center, np.float64).reshape(4))    # epipole
+        if abs(e[2]) > 1e-9 * (abs(e[0]) + abs(e[1]) + 1e-30):
+            v = e[:2] / e[2] - np.array([W / 2.0, H / 2.0])
+        else:
+            v = e[:2]
+        nrm = np.hypot(v[0], v[1]) + 1e-30
+        dx += abs(v[0]) / nrm
+        dy += abs(v[1]) / nrm
+    if dy >= dx:
+        return None              # lines run along image columns: ray_idx order already does
+    r = ray_idxs.to(torch.int64)
+    key = (r % H) * W + (r // H)  # row-major position of pixel (x = idx / H, y = idx % H)
+    return torch.argsort(key).to(torch.int32)
 
 
 def shard_bounds(n, rank, world):
@@ -200,6 +229,8 @@ class RayNetForwardPass(ForwardPass):
         # world_size-2 gloo test injects a host stand-in to exercise the sharding and
         # all-reduce logic without a GPU.)
         self._backend_factory = backend_factory
+        # schedule knob only; results do not depend on it (RAYNET_SWEEP_REORDER=0 for A/B runs)
+        self.sweep_reorder = os.environ.get("RAYNET_SWEEP_REORDER", "1") != "0"
         self.ref_idx = -1
         self._ctx = None
         self._de = None
@@ -297,8 +328,10 @@ class RayNetForwardPass(ForwardPass):
                       msgs=torch.zeros((n, M), dtype=torch.float32, device=dev))
             B = self.rays_batch if self.rays_batch else n
             for i in range(0, n, B):
+                order = sweep_order(ridx[i:i + B], H, W, images) if self.sweep_reorder else None
                 ctx.scene_prepare(ridx[i:i + B], [bank[v] for v in views], P, P_inv, center,
-                                  st["vox"][i:i + B], st["rvc"][i:i + B], st["Sr"][i:i + B])
+                                  st["vox"][i:i + B], st["rvc"][i:i + B], st["Sr"][i:i + B],
+                                  order=order)
             per_image[r] = st
 
         for it in range(self.bp_iterations):

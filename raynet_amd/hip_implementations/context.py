@@ -195,12 +195,13 @@ class HipContext(object):
             _ptr(depth_map), _stream()))
 
     # -- resident-scene path ---------------------------------------------------
-    def scene_prepare(self, ray_idxs, feature_views, P, P_inv, center, vox, rvc, Sr):
+    def scene_prepare(self, ray_idxs, feature_views, P, P_inv, center, vox, rvc, Sr, order=None):
         assert len(feature_views) == self.N
+        assert order is None or (order.dtype == torch.int32 and len(order) == len(ray_idxs))
         arr = (ctypes.c_void_p * self.N)(*[fv.data_ptr() for fv in feature_views])
         self._check(self.lib.rn_scene_prepare(self._h, len(ray_idxs), _ptr(ray_idxs), arr, _ptr(P),
-                                              _ptr(P_inv), _ptr(center), _ptr(vox), _ptr(rvc),
-                                              _ptr(Sr), _stream()))
+                                              _ptr(P_inv), _ptr(center), _ptr(order), _ptr(vox),
+                                              _ptr(rvc), _ptr(Sr), _stream()))
 
     def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part):
         self._check(self.lib.rn_scene_bp_sweep(self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc),

@@ -38,7 +38,7 @@ class OracleBackend(object):
         return np.ascontiguousarray(np.stack([v >> 20, (v >> 10) & 1023, v & 1023], axis=-1)
                                     .astype(np.int32))
 
-    def scene_prepare(self, ridx, feature_views, P, P_inv, center, vox, rvc, Sr):
+    def scene_prepare(self, ridx, feature_views, P, P_inv, center, vox, rvc, Sr, order=None):
         feats = np.stack([f.numpy() for f in feature_views])
         s, e = self.o.sample(ridx.numpy(), P_inv.numpy(), center.numpy())
         S = self.o.similarities(feats, P.numpy(), s, e)

@@ -497,6 +497,35 @@ def test_resident_scene_path_equals_fused(torch, oracle_mod, case):
     assert (np.abs(depth.cpu().numpy() - depth_o) > 1e-4).mean() <= 0.02
 
 
+def test_sweep_order_changes_only_the_schedule(torch, oracle_mod):
+    """rn_scene_prepare with a permutation `order` writes bit-identical columns."""
+    c = CU["wide"]
+    o, feats, vg = make_case(oracle_mod, c)
+    ctx = hip_ctx(o)
+    ctx.set_voxel_grid(torch.from_numpy(vg).cuda())
+    n = len(c["ray_idxs"])
+    ridx = ctx.dev(c["ray_idxs"])
+    fv = [torch.from_numpy(feats).cuda()[v] for v in range(o.N)]
+    P, Pi, cc = ctx.dev(c["P"]), ctx.dev(c["P_inv"]), ctx.dev(c["center"])
+    outs = []
+    for order in (None, torch.randperm(n, device="cuda").to(torch.int32)):
+        vox = torch.zeros((n, o.M), dtype=torch.int32, device="cuda")
+        rvc = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        Sr = torch.zeros((n, o.M), device="cuda")
+        ctx.scene_prepare(ridx, fv, P, Pi, cc, vox, rvc, Sr, order=order)
+        outs.append((vox.cpu().numpy(), rvc.cpu().numpy(), Sr.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    from raynet_amd.forward_pass import sweep_order
+    from raynet_amd.synthetic import make_synthetic_scene
+    scene, _ = make_synthetic_scene(H=12, W=16, n_views=5, focal=18.0)
+    full = torch.arange(12 * 16, dtype=torch.int32, device="cuda")
+    order = sweep_order(full, 12, 16, scene.get_image_with_neighbors(0, 4))
+    assert order is not None and sorted(order.cpu().tolist()) == list(range(12 * 16))
+    # cameras on a horizontal ring: epipolar lines run along image rows -> row-major walk
+    assert order[:16].cpu().tolist() == [x * 12 for x in range(16)]
+
+
 def test_mvcnn_kernels_k9_to_k12(torch, oracle_mod):
     from raynet_amd.hip_implementations.similarities import \
         perform_multi_view_cnn_forward_pass, \
