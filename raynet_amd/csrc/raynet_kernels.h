@@ -234,16 +234,22 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
                 const int o = __shfl(off[v], src);
                 f[v] = *reinterpret_cast<const float4 *>(fv.v[v] + o + 4 * part);
             }
+            // the only place where multiply-adds may fuse: 4-term partial dot products whose
+            // order already differs from the reference's serial sum (tolerance-tested);
+            // halves the VALU work of the kernel's hottest loop
             float acc = 0.0f;
+            {
+#pragma clang fp contract(fast)
 #pragma unroll
-            for (int i = 0; i < NV; i++) {
+                for (int i = 0; i < NV; i++) {
 #pragma unroll
-                for (int j = i + 1; j < NV; j++) {
-                    float d = f[i].x * f[j].x;
-                    d += f[i].y * f[j].y;
-                    d += f[i].z * f[j].z;
-                    d += f[i].w * f[j].w;
-                    acc += d;
+                    for (int j = i + 1; j < NV; j++) {
+                        float d = f[i].x * f[j].x;
+                        d = f[i].y * f[j].y + d;
+                        d = f[i].z * f[j].z + d;
+                        d = f[i].w * f[j].w + d;
+                        acc += d;
+                    }
                 }
             }
 #pragma unroll
