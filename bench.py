@@ -92,9 +92,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # one rank per GPU; RAYNET_DIST_BACKEND=gloo lets several ranks share one GPU for
+    # functional tests of the sharded path on a single-GPU box (RCCL refuses that)
+    backend = os.environ.get("RAYNET_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     _lib.load()     # fails loudly if the HIP library was not built
 
     cfg = CONFIGS[args.config]

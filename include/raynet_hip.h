@@ -115,7 +115,8 @@ int rn_planes_to_voxels(rn_ctx *ctx, int32_t n, const int32_t *rvi, const int32_
                         const float *ray_start, const float *ray_end, const float *S,
                         float *S_new, void *stream);
 
-/* K3 batch_belief_propagation, launcher mrf_cuda.py:37-79 */
+/* K3 batch_belief_propagation, launcher mrf_cuda.py:37-79.
+ * msgs_in may be NULL: all-zero messages (then msgs_out is only written). */
 int rn_bp_sweep(rn_ctx *ctx, int32_t n, const float *S, const int32_t *rvi, const int32_t *rvc,
                 const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
                 void *stream);
@@ -187,9 +188,11 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
 /* acc_part: [rn_acc_copies()][gx][gy][gz] f32, zero before the first sweep of an
  * iteration; messages are scattered into one copy per XCD. */
 int rn_acc_copies(const rn_ctx *ctx);
+/* first_sweep != 0: the messages are taken as zero and `msgs` is only written, so it
+ * needs no zero-fill (the reference zero-fills for iteration 0, forward_pass.py:613-615). */
 int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                       const int32_t *rvc, const float *acc_in, float *msgs, float *acc_part,
-                      void *stream);
+                      int32_t first_sweep, void *stream);
 /* acc_out = prior + sum over copies (+ optionally `extra`, e.g. nothing or a
  * peer's partial); the copies are zeroed for the next iteration. */
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream);

@@ -81,7 +81,7 @@ SIGNATURES = {
     "rn_fused_depth": [_P, _I] + [_P] * 12,
     "rn_scene_prepare": [_P, _I, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P],
     "rn_acc_copies": [_P],
-    "rn_scene_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "rn_scene_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "rn_acc_combine": [_P, _P, _F, _P, _P],
     "rn_acc_reduce_local": [_P, _P, _P, _P],
     "rn_acc_add_prior": [_P, _P, _F, _P],

@@ -253,11 +253,24 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
 // One wavefront per ray, NCH chunks of 64 voxels held in registers.
 //   CLIP_IN: S is the raw voxel-space column (API mode) and is clipped +
 //            renormalised here; otherwise it is the resident Sr.
-//   acc_out may be one of several per-XCD copies (xcd_stride != 0).
 //   SCATTER: add the messages to acc_out with one atomic per voxel from this kernel
 //            (lanes = consecutive voxels of ONE ray: 64 different cache lines per
-//            instruction).  The drivers use SCATTER=false + k_scatter_tile instead.
-template <int NCH, bool PACKED, bool CLIP_IN, bool XCD_LOCAL, bool SCATTER>
+//            instruction).  The drivers use SCATTER=false + k_scatter_slab instead.
+//   msgs_in == nullptr means "all messages are zero" (first sweep): nothing is read.
+// The kernel is latency bound (about three dependent memory round trips per ray), so the
+// rows of the first SPEC chunks are requested before the ray's voxel count is known: the
+// rows are M long for every ray, entries past the count are loaded and ignored.
+constexpr int SPEC = 2;
+template <bool PACKED>
+__device__ __forceinline__ int load_packed(const int32_t *__restrict__ row, int i) {
+    if (PACKED) return row[i];
+    return pack_voxel(row[3 * i], row[3 * i + 1], row[3 * i + 2]);
+}
+__device__ __forceinline__ int lin_of(const Params &p, int v) {
+    return ((v >> 20) * p.gy + ((v >> 10) & 1023)) * p.gz + (v & 1023);
+}
+
+template <int NCH, bool PACKED, bool CLIP_IN, bool SCATTER>
 __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
                                               const int32_t *__restrict__ vox,
                                               const int32_t *__restrict__ rvc,
@@ -267,31 +280,66 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
     int lane;
     const int r = ray_of_wave(n, lane);
     if (r < 0) return;
-    const int count = min(uniform(rvc[r]), p.M);
-    if (count <= 1) return;   // mrf_np.py:300 (SURVEY.md Q4)
     const float *Srow = S + (size_t)r * p.M;
     const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
-    const float *min_row = msgs_in + (size_t)r * p.M;
+    const float *min_row = msgs_in ? msgs_in + (size_t)r * p.M : nullptr;
     float *mout_row = msgs_out + (size_t)r * p.M;
+
+    float sv[NCH], mv[NCH];
+    int pk[NCH];
+    // speculative rows
+#pragma unroll
+    for (int ch = 0; ch < NCH && ch < SPEC; ch++) {
+        const int i = ch * WAVE + lane;
+        sv[ch] = 0.0f; mv[ch] = 0.0f; pk[ch] = 0;
+        if (i < p.M) {
+            sv[ch] = Srow[i];
+            pk[ch] = load_packed<PACKED>(vrow, i);
+            if (min_row) mv[ch] = min_row[i];
+        }
+    }
+    const int count = min(uniform(rvc[r]), p.M);
+    if (count <= 1) return;   // mrf_np.py:300 (SURVEY.md Q4)
     if (xcd_stride) {
         // the XCD this workgroup really runs on; copies are private per XCD
         const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
         acc_out += xcc * xcd_stride;
     }
-
-    float sv[NCH], ov[NCH], tsv[NCH], cex[NCH], wv[NCH];
+#pragma unroll
+    for (int ch = SPEC; ch < NCH; ch++) {
+        const int i = ch * WAVE + lane;
+        sv[ch] = 0.0f; mv[ch] = 0.0f; pk[ch] = 0;
+        if (ch * WAVE < count && i < count) {
+            sv[ch] = Srow[i];
+            pk[ch] = load_packed<PACKED>(vrow, i);
+            if (min_row) mv[ch] = min_row[i];
+        }
+    }
+    // accumulator gather (depends on the voxel rows)
+    float av[NCH];
     int lin[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        const int i = ch * WAVE + lane;
+        av[ch] = 0.0f;
+        lin[ch] = 0;
+        if (ch * WAVE < count && i < count) {
+            lin[ch] = lin_of(p, pk[ch]);
+            av[ch] = acc_in[lin[ch]];
+        }
+    }
+
     float ssum = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         const int i = ch * WAVE + lane;
-        sv[ch] = 0.0f;
-        if (ch * WAVE < count && i < count) {
-            float v = Srow[i];
+        float v = 0.0f;
+        if (i < count) {
+            v = sv[ch];
             if (CLIP_IN) v = clampf(v, (float)1e-5, (float)(1 - 1e-5));
-            sv[ch] = v;
-            ssum += v;
         }
+        sv[ch] = v;
+        ssum += v;
     }
     if (CLIP_IN) {
         ssum = wave_sum(ssum);
@@ -300,20 +348,15 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
     }
 
     // pass A: occupancy, exclusive cumprod T, w = o*T*s, exclusive cumsum C
+    float ov[NCH], tsv[NCH], cex[NCH], wv[NCH];
     float carryT = 1.0f, carryC = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
+        ov[ch] = 0.0f; tsv[ch] = 0.0f; cex[ch] = 0.0f; wv[ch] = 0.0f;
         if (ch * WAVE < count) {
             const int i = ch * WAVE + lane;
             const bool valid = i < count;
-            float o = 0.0f;
-            lin[ch] = 0;
-            if (valid) {
-                int x, y, z;
-                load_voxel<PACKED>(vrow, i, x, y, z);
-                lin[ch] = (x * p.gy + y) * p.gz + z;
-                o = occupancy_to_ray(acc_in[lin[ch]], min_row[i]);
-            }
+            const float o = valid ? occupancy_to_ray(av[ch], mv[ch]) : 0.0f;
             const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
             const float T = carryT * wave_shift1(incl, 1.0f);
             carryT = carryT * lane63(incl);
@@ -346,7 +389,7 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
         }
     }
 
-    // pass B: messages (mrf_bp.cu:136-167) and scatter (:170-176)
+    // pass B: messages (mrf_bp.cu:136-167) and, optionally, the scatter (:170-176)
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         if (ch * WAVE < count) {
@@ -357,11 +400,7 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
                 pos = pos / (pos + neg);
                 const float m = logf(pos) - logf(1.0f - pos);
                 mout_row[i] = m;
-                if (!SCATTER) continue;
-                if (XCD_LOCAL)   // copy private to this XCD: its own L2 is the coherence point
-                    __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                else
+                if (SCATTER)
                     __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -657,26 +696,57 @@ __global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S
     int lane;
     const int r = ray_of_wave(n, lane);
     if (r < 0) return;
-    const int count = min(uniform(rvc[r]), p.M);
     const float *Srow = S + (size_t)r * p.M;
     const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
     const float *mrow = msgs + (size_t)r * p.M;
 
+    // rows of the first SPEC chunks are requested before the count is known (see k_bp)
+    float sv[NCH], mv[NCH];
+    int pk[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH && ch < SPEC; ch++) {
+        const int i = ch * WAVE + lane;
+        sv[ch] = 0.0f; mv[ch] = 0.0f; pk[ch] = 0;
+        if (i < p.M) {
+            sv[ch] = Srow[i];
+            pk[ch] = load_packed<PACKED>(vrow, i);
+            mv[ch] = mrow[i];
+        }
+    }
+    const int count = min(uniform(rvc[r]), p.M);
+
     float best = -INFINITY;
     int best_i = 0;
     if (count > 1) {
-        float sv[NCH], wv[NCH];
+#pragma unroll
+        for (int ch = SPEC; ch < NCH; ch++) {
+            const int i = ch * WAVE + lane;
+            sv[ch] = 0.0f; mv[ch] = 0.0f; pk[ch] = 0;
+            if (ch * WAVE < count && i < count) {
+                sv[ch] = Srow[i];
+                pk[ch] = load_packed<PACKED>(vrow, i);
+                mv[ch] = mrow[i];
+            }
+        }
+        float av[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const int i = ch * WAVE + lane;
+            av[ch] = 0.0f;
+            if (ch * WAVE < count && i < count) av[ch] = acc[lin_of(p, pk[ch])];
+        }
+        float wv[NCH];
         float ssum = 0.0f;
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {
             const int i = ch * WAVE + lane;
-            sv[ch] = 0.0f;
-            if (ch * WAVE < count && i < count) {
-                float v = Srow[i];
+            float v = 0.0f;
+            if (i < count) {
+                v = sv[ch];
                 if (CLIP_IN) v = clampf(v, (float)1e-5, (float)(1 - 1e-5));
-                sv[ch] = v;
-                ssum += v;
             }
+            sv[ch] = v;
+            ssum += v;
         }
         if (CLIP_IN) {
             ssum = wave_sum(ssum);
@@ -690,12 +760,7 @@ __global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S
             if (ch * WAVE < count) {
                 const int i = ch * WAVE + lane;
                 const bool valid = i < count;
-                float o = 0.0f;
-                if (valid) {
-                    int x, y, z;
-                    load_voxel<PACKED>(vrow, i, x, y, z);
-                    o = occupancy_to_ray(acc[(x * p.gy + y) * p.gz + z], mrow[i]);
-                }
+                const float o = valid ? occupancy_to_ray(av[ch], mv[ch]) : 0.0f;
                 const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
                 const float T = carryT * wave_shift1(incl, 1.0f);
                 carryT = carryT * lane63(incl);
@@ -929,11 +994,11 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
 #define RN_BP(NCH_)                                                                         \
     do {                                                                                    \
         if (fused)                                                                          \
-            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, false, true>), dim3(ray_blocks(n)), \
+            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, true>), dim3(ray_blocks(n)), \
                                dim3(BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in,  \
                                acc_out, msgs_out, xcd_stride);                               \
         else                                                                                \
-            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, false, false>),                   \
+            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, false>),                   \
                                dim3(ray_blocks(n)), dim3(BLOCK), 0, st, ctx->p, n, Sv, vox,   \
                                rvc, acc_in, msgs_in, acc_out, msgs_out, xcd_stride);         \
     } while (0)
@@ -1154,8 +1219,8 @@ int rn_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sv, const int32_t *rvi, con
                 const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
                 void *stream) {
     if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
-    if (!ctx || n < 0 || !Sv || !rvi || !rvc || !acc_in || !msgs_in || !acc_out || !msgs_out)
-        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (!ctx || n < 0 || !Sv || !rvi || !rvc || !acc_in || !acc_out || !msgs_out)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");   /* msgs_in == NULL: all-zero messages */
     if (n == 0) return RN_OK;
     return launch_bp<false, true>(ctx, n, Sv, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
                                   S(stream));
@@ -1320,14 +1385,14 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
 
 int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                       const int32_t *rvc, const float *acc_in, float *msgs, float *acc_part,
-                      void *stream) {
+                      int32_t first_sweep, void *stream) {
     if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc_in || !msgs || !acc_part)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
     const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
-    return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, msgs, acc_part, msgs,
-                                  ctx->acc_mode == 1 ? G : 0, S(stream));
+    return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, first_sweep ? nullptr : msgs,
+                                  acc_part, msgs, ctx->acc_mode == 1 ? G : 0, S(stream));
 }
 
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream) {

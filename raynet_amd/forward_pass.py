@@ -337,13 +337,14 @@ class RayNetForwardPass(ForwardPass):
         for it in range(self.bp_iterations):
             for r in refs:
                 st = per_image[r]
-                if self.reference_quirks and it > 0:
-                    st["msgs"].zero_()       # memmap reopened with mode="w+" 
+                # iteration 0 starts from zero messages (forward_pass.py:613-615); with the
+                # shipped quirk every iteration does (memmap reopened with mode="w+", Q1)
+                first = it == 0 or self.reference_quirks
                 n = st["n"]
                 B = self.rays_batch if self.rays_batch else n
                 for i in range(0, n, B):
                     ctx.scene_bp_sweep(st["Sr"][i:i + B], st["vox"][i:i + B], st["rvc"][i:i + B],
-                                       acc_in, st["msgs"][i:i + B], acc_part)
+                                       acc_in, st["msgs"][i:i + B], acc_part, first_sweep=first)
             # swap + prior refill of forward_pass.py:676-678; across ranks the prior is
             # added once, after the sum
             if world > 1:

@@ -48,7 +48,9 @@ class OracleBackend(object):
         rvc.numpy()[...] = cnt
         Sr.numpy()[...] = Sv        # clipped + renormalised inside the oracle's BP / depth calls
 
-    def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part):
+    def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False):
+        if first_sweep:
+            msgs.zero_()
         m = np.ascontiguousarray(msgs.numpy())
         out = np.ascontiguousarray(acc_part[0].numpy())
         self.o.bp_sweep(Sr.numpy(), self._unpack(vox), rvc.numpy(), acc_in.numpy(), m, out)

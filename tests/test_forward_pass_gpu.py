@@ -185,3 +185,56 @@ def test_full_size_properties(torch):
     depths2 = list(fp2.forward_pass(scene, (0, 2, 1)))
     assert float((fp2.accumulator - acc).abs().max()) < 1e-2
     assert (np.abs(depths2[0] - depths[0]) > 1e-4).mean() < 1e-3
+
+
+def _rank_main(rank, world, port, out_dir):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                                world_size=world)
+    H, W = 48, 64
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    fp = get_forward_pass_factory("raynet")(bank, _gp(32, 192, (64, 64, 64)), "sample_in_bbox",
+                                            (H, W), 0)
+    depths = list(fp.forward_pass(scene, (0, 5, 1)))
+    np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), depth=np.stack(depths),
+             acc=fp.accumulator.cpu().numpy())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_sharded_ranks_on_real_kernels(torch, tmp_path):
+    """Two ranks (gloo, both on cuda:0 -- RCCL needs one GPU per rank) run the real HIP
+    kernels on their ray shards; the merged accumulator and depth maps equal the
+    single-rank run (prior counted once)."""
+    import socket
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_main, args=(0, 1, 0, out))]
+    procs[0].start()
+    procs[0].join(300)
+    assert procs[0].exitcode == 0
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    one = np.load(out + "/w1_r0.npz")
+    r0, r1 = np.load(out + "/w2_r0.npz"), np.load(out + "/w2_r1.npz")
+    assert np.array_equal(r0["acc"], r1["acc"]) and np.array_equal(r0["depth"], r1["depth"])
+    assert np.abs(one["acc"] - r0["acc"]).max() < 5e-3
+    assert (np.abs(one["depth"] - r0["depth"]) > 1e-4).mean() < 0.01
