@@ -50,14 +50,14 @@ def _dist():
     return None, 0, 1
 
 
-def sweep_order(ray_idxs, H, W, images):
-    """Schedule of the plane sweep: the order in which the wavefronts take the rays.
+def sweep_direction(H, W, images):
+    """"rows" if the epipolar lines of the neighbour views run along image rows of the
+    reference view, else "cols".
 
     A ray reads the feature vectors along its epipolar line in every neighbour view.
     Rays whose pixels lie ALONG an epipolar line share those lines, so walking the
     image in that direction keeps a few feature rows per view hot in the XCD's L2
-    instead of streaming the whole map for every image column.  Returns an int32
-    permutation (CUDA tensor) or None for the natural (column-major) order."""
+    instead of streaming the whole map for every image column."""
     ref = images[0].camera
     P = np.asarray(ref.P, np.float64)
     dx = dy = 0.0
@@ -70,11 +70,22 @@ def sweep_order(ray_idxs, H, W, images):
         nrm = np.hypot(v[0], v[1]) + 1e-30
         dx += abs(v[0]) / nrm
         dy += abs(v[1]) / nrm
-    if dy >= dx:
-        return None              # lines run along image columns: ray_idx order already does
+    return "rows" if dx > dy else "cols"
+
+
+def row_major_order(ray_idxs, H, W):
+    """int32 permutation that visits the rays in row-major pixel order
+    (pixel x = idx / H, y = idx % H, sampling_schemes.cu:5-8)."""
     r = ray_idxs.to(torch.int64)
-    key = (r % H) * W + (r // H)  # row-major position of pixel (x = idx / H, y = idx % H)
-    return torch.argsort(key).to(torch.int32)
+    return torch.argsort((r % H) * W + (r // H)).to(torch.int32)
+
+
+def sweep_order(ray_idxs, H, W, images):
+    """Schedule of the plane sweep (see sweep_direction): a permutation, or None for the
+    natural column-major order of ray indices."""
+    if sweep_direction(H, W, images) == "rows":
+        return row_major_order(ray_idxs, H, W)
+    return None
 
 
 def shard_bounds(n, rank, world):
@@ -311,24 +322,54 @@ class RayNetForwardPass(ForwardPass):
         acc_part = torch.zeros((copies,) + tuple(G), dtype=torch.float32, device=dev)
         acc_next = torch.empty(G, dtype=torch.float32, device=dev)
 
+        # all camera matrices go up in ONE copy before the first launch: a pageable
+        # host->device copy is a stream synchronisation point, and one per image would
+        # drain the GPU between images
+        N = gp.neighbors + 1
+        stride = 12 * N + 12 + 4
+        cam_host = np.zeros((len(refs), stride), dtype=np.float32)
+        views_of = {}
+        for k, r in enumerate(refs):
+            views_of[r] = scene.view_indices_with_neighbors(r, gp.neighbors)
+            P, P_inv, center = self._camera_arrays([scene.get_image(v) for v in views_of[r]])
+            cam_host[k, :12 * N] = P.ravel()
+            cam_host[k, 12 * N:12 * N + 12] = P_inv.ravel()
+            cam_host[k, 12 * N + 12:] = center
+        cam_dev = ctx.dev(cam_host)
+
         # K1 prefix once per reference image; columns stay resident
         per_image = {}
-        for r in refs:
-            ray_idxs = self.get_valid_rays_per_image(scene, r)
-            lo, hi = shard_bounds(len(ray_idxs), rank, world)
-            ridx = ctx.dev(np.ascontiguousarray(ray_idxs[lo:hi].astype(np.int32)))
+        orders = {}
+        for k, r in enumerate(refs):
+            if self._filter_out_rays:
+                ray_idxs = self.get_valid_rays_per_image(scene, r)
+                total = len(ray_idxs)
+                lo, hi = shard_bounds(total, rank, world)
+                ridx = ctx.dev(np.ascontiguousarray(ray_idxs[lo:hi].astype(np.int32)))
+            else:       # all H*W rays (forward_pass.py:166-168): built on the device
+                total = H * W
+                lo, hi = shard_bounds(total, rank, world)
+                ridx = torch.arange(lo, hi, dtype=torch.int32, device=dev)
             n = len(ridx)
-            views = scene.view_indices_with_neighbors(r, gp.neighbors)
+            views = views_of[r]
             images = [scene.get_image(v) for v in views]
-            P, P_inv, center = (ctx.dev(a) for a in self._camera_arrays(images))
-            st = dict(ridx=ridx, n=n, lo=lo, hi=hi, total=len(ray_idxs), center=center,
+            P = cam_dev[k, :12 * N]
+            P_inv = cam_dev[k, 12 * N:12 * N + 12]
+            center = cam_dev[k, 12 * N + 12:]
+            st = dict(ridx=ridx, n=n, lo=lo, hi=hi, total=total, center=center,
                       vox=torch.empty((n, M), dtype=torch.int32, device=dev),
                       rvc=torch.empty((n,), dtype=torch.int32, device=dev),
                       Sr=torch.empty((n, M), dtype=torch.float32, device=dev),
                       msgs=torch.zeros((n, M), dtype=torch.float32, device=dev))
             B = self.rays_batch if self.rays_batch else n
             for i in range(0, n, B):
-                order = sweep_order(ridx[i:i + B], H, W, images) if self.sweep_reorder else None
+                order = None
+                if self.sweep_reorder:
+                    mode = sweep_direction(H, W, images)
+                    key = (mode, lo + i, min(lo + i + B, hi))
+                    if mode == "rows" and (self._filter_out_rays or key not in orders):
+                        orders[key] = row_major_order(ridx[i:i + B], H, W)
+                    order = orders.get(key) if mode == "rows" else None
                 ctx.scene_prepare(ridx[i:i + B], [bank[v] for v in views], P, P_inv, center,
                                   st["vox"][i:i + B], st["rvc"][i:i + B], st["Sr"][i:i + B],
                                   order=order)
@@ -356,7 +397,10 @@ class RayNetForwardPass(ForwardPass):
             acc_in, acc_next = acc_next, acc_in
         self.accumulator = acc_in
 
+        # depth sweep: all launches and device->host copies are queued first, then the maps
+        # are handed out in order (the reference yields after each image's `.get()`)
         last = per_image[refs[-1]] if refs else None
+        pending = []
         for r in refs:
             st = per_image[r]
             msgs = st["msgs"]
@@ -371,15 +415,25 @@ class RayNetForwardPass(ForwardPass):
                                 depth[st["lo"] + i:st["lo"] + min(i + B, n)])
             if world > 1:
                 dist.all_reduce(depth, op=dist.ReduceOp.SUM)   # disjoint slices, zeros elsewhere
+            host = torch.empty((st["total"],), dtype=torch.float32, pin_memory=dev.type == "cuda")
+            host.copy_(depth, non_blocking=True)
+            done = torch.cuda.Event() if dev.type == "cuda" else None
+            if done is not None:
+                done.record()
+            pending.append((r, host, done))
             self.messages[r] = st["msgs"]
             self.voxel_count[r] = st["rvc"]
+        for r, host, done in pending:
+            if done is not None:
+                done.synchronize()
             self.ref_idx = r
+            d = host.numpy()
             if self._filter_out_rays:
                 full = np.zeros((H * W,), dtype=np.float32)
-                full[self.get_valid_rays_per_image(scene, r)] = depth.cpu().numpy()
+                full[self.get_valid_rays_per_image(scene, r)] = d
                 yield full.reshape(W, H).T
             else:
-                yield depth.cpu().numpy().reshape(W, H).T
+                yield d.reshape(W, H).T
 
     def _forward_pass_reference(self, scene, images_range):
         """Literal schedule of forward_pass.py:579-748 with K1 / K2 (single rank)."""
