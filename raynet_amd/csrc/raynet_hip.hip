@@ -104,37 +104,132 @@ __global__ void k_sample_points(Params p, int n, const int32_t *__restrict__ ray
 }
 
 // ------------------------------------------------------------ K5 traversal
-// One thread per ray.  Source of the segment: explicit starts/ends, or the
+// One thread per ray (the DDA is a chain of sequential fp32 additions, bit-exactness
+// forbids re-associating it).  Source of the segment: explicit starts/ends, or the
 // camera (sample_in_bbox), as in the fused kernels.
+// A thread writing its own row step by step produces one partial-line write per voxel
+// (4x write amplification measured).  Each 64-thread block therefore collects
+// [64 rays][TRAV_TILE steps] in LDS and writes finished tiles as coalesced row segments.
+constexpr int TRAV_TILE = 32;
 template <bool PACKED>
-__global__ void k_traverse(Params p, int n, const int32_t *__restrict__ ray_idxs,
-                           const float *__restrict__ P_inv, const float *__restrict__ cc,
-                           const float *__restrict__ starts, const float *__restrict__ ends,
-                           int32_t *vox, int32_t *rvc) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    float s[3], e[3];
-    if (ray_idxs) {
-        sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
-    } else {
-        for (int i = 0; i < 3; i++) {
-            s[i] = starts[3 * r + i];
-            e[i] = ends[3 * r + i];
+__global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
+                                                   const int32_t *__restrict__ ray_idxs,
+                                                   const float *__restrict__ P_inv,
+                                                   const float *__restrict__ cc,
+                                                   const float *__restrict__ starts,
+                                                   const float *__restrict__ ends, int32_t *vox,
+                                                   int32_t *rvc) {
+    __shared__ int32_t tile[WAVE * (TRAV_TILE + 1)];
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.x * WAVE;
+    const int r = r0 + lane;
+    const bool live = r < n;
+    float s[3] = {0.f, 0.f, 0.f}, e[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        if (ray_idxs) {
+            sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+        } else {
+            for (int i = 0; i < 3; i++) {
+                s[i] = starts[3 * r + i];
+                e[i] = ends[3 * r + i];
+            }
         }
     }
-    int count;
-    if (PACKED) {
-        int32_t *row = vox + (size_t)r * p.M;
-        count = dda(p, s, e, [&](int i, int x, int y, int z) { row[i] = pack_voxel(x, y, z); });
-    } else {
-        int32_t *row = vox + (size_t)r * p.M * 3;
-        count = dda(p, s, e, [&](int i, int x, int y, int z) {
-            row[3 * i] = x;
-            row[3 * i + 1] = y;
-            row[3 * i + 2] = z;
-        });
+    // ---- DDA set-up (ray_tracing.pyx:99-161), identical arithmetic to rn::dda
+    const float EPS = 1e-2f;
+    const int g[3] = {p.gx, p.gy, p.gz};
+    float ss[3], ee[3], bin[3], ray[3], tm[3], td[3];
+    int step[3], cur[3], last[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ss[i] = s[i] - p.bbox[i];
+        ee[i] = e[i] - p.bbox[i];
+        bin[i] = (p.bbox[3 + i] - p.bbox[i]) / g[i];
+        ray[i] = ee[i] - ss[i];
+        step[i] = ray[i] >= 0 ? 1 : -1;
     }
-    rvc[r] = count;   // written even when 0
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ss[i] += step[i] * bin[i] * EPS;
+        ee[i] -= step[i] * bin[i] * EPS;
+        cur[i] = (int)floorf(ss[i] / bin[i]);
+        last[i] = (int)floorf(ee[i] / bin[i]);
+    }
+    bool active = live && !(cur[0] < 0 || cur[0] >= g[0] || cur[1] < 0 || cur[1] >= g[1] ||
+                            cur[2] < 0 || cur[2] >= g[2]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        tm[i] = FLT_MAX;
+        if (ray[i] != 0) {
+            const float c = cur[i] * bin[i];
+            float b;
+            if (step[i] < 0 && c < ss[i])
+                b = c;
+            else
+                b = c + step[i] * bin[i];
+            tm[i] = (b - ss[i]) / ray[i];
+        }
+        td[i] = ray[i] != 0 ? step[i] * bin[i] / ray[i] : FLT_MAX;
+    }
+    int cx = cur[0], cy = cur[1], cz = cur[2];
+    float tx = tm[0], ty = tm[1], tz = tm[2];
+    int count = 0;           // voxels emitted so far by this ray
+    // `active` = this ray still has a voxel (cx,cy,cz) to emit at index `count`
+    for (int base = 0; base < p.M; base += TRAV_TILE) {
+        if (__ballot(active) == 0) break;
+        for (int k = 0; k < TRAV_TILE && base + k < p.M; k++) {
+            if (active) {
+                tile[lane * (TRAV_TILE + 1) + k] = pack_voxel(cx, cy, cz);
+                count++;
+                // advance (ray_tracing.pyx:166-197)
+                if ((cx == last[0] && cy == last[1] && cz == last[2]) || count >= p.M) {
+                    active = false;
+                } else if (tx < ty) {
+                    if (tx < tz) {
+                        cx += step[0];
+                        if (cx < 0 || cx >= g[0]) active = false;
+                        tx += td[0];
+                    } else {
+                        cz += step[2];
+                        if (cz < 0 || cz >= g[2]) active = false;
+                        tz += td[2];
+                    }
+                } else {
+                    if (ty < tz) {
+                        cy += step[1];
+                        if (cy < 0 || cy >= g[1]) active = false;
+                        ty += td[1];
+                    } else {
+                        cz += step[2];
+                        if (cz < 0 || cz >= g[2]) active = false;
+                        tz += td[2];
+                    }
+                }
+            }
+        }
+        wave_sync();
+        // flush: TRAV_TILE consecutive steps of one ray are one contiguous segment
+        constexpr int RPI = WAVE / TRAV_TILE;      // rows per instruction
+#pragma unroll 4
+        for (int j = 0; j < WAVE; j += RPI) {
+            const int row = j + lane / TRAV_TILE;
+            const int col = lane % TRAV_TILE;
+            const int c = __shfl(count, row);
+            if (r0 + row < n && base + col < c) {
+                const int v = tile[row * (TRAV_TILE + 1) + col];
+                const size_t off = (size_t)(r0 + row) * p.M + base + col;
+                if (PACKED) {
+                    vox[off] = v;
+                } else {
+                    vox[3 * off] = v >> 20;
+                    vox[3 * off + 1] = (v >> 10) & 1023;
+                    vox[3 * off + 2] = v & 1023;
+                }
+            }
+        }
+        wave_sync();
+    }
+    if (live) rvc[r] = count;   // written even when 0
 }
 
 // ---------------------------------------- plane sweep (+ mapping) per wavefront
@@ -260,7 +355,10 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
 // The kernel is latency bound (about three dependent memory round trips per ray), so the
 // rows of the first SPEC chunks are requested before the ray's voxel count is known: the
 // rows are M long for every ray, entries past the count are loaded and ignored.
-constexpr int SPEC = 2;
+#ifndef RN_SPEC
+#define RN_SPEC 1
+#endif
+constexpr int SPEC = RN_SPEC;   // chunks whose rows are requested before the count is known
 template <bool PACKED>
 __device__ __forceinline__ int load_packed(const int32_t *__restrict__ row, int i) {
     if (PACKED) return row[i];
@@ -396,9 +494,9 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
             const int i = ch * WAVE + lane;
             if (i < count) {
                 float pos = cex[ch] + tsv[ch];
-                const float neg = cex[ch] + suf[ch] / (1.0f - ov[ch]);
-                pos = pos / (pos + neg);
-                const float m = logf(pos) - logf(1.0f - pos);
+                const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
+                pos = bp_div(pos, pos + neg);
+                const float m = bp_log(pos) - bp_log(1.0f - pos);
                 mout_row[i] = m;
                 if (SCATTER)
                     __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
@@ -494,7 +592,10 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_tile(Params p, int n,
 #ifdef RN_SCATTER_STATS
 __device__ unsigned long long g_scatter_stats[8];   // rounds, emitting lanes, tails, 64B segments, chunks
 #endif
-constexpr int SLAB_STEPS = 32;
+#ifndef RN_SLAB_STEPS
+#define RN_SLAB_STEPS 32
+#endif
+constexpr int SLAB_STEPS = RN_SLAB_STEPS;     // steps of a tile: 16, 32 or 64
 constexpr int SLAB_PAD = SLAB_STEPS + 1;
 template <bool PACKED>
 __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
@@ -554,12 +655,15 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
         if (PACKED && (p.M % SLAB_STEPS) == 0) {
             // rows in: 8 rays per instruction, each lane 4 consecutive steps (16 B); all 16
             // loads of the chunk are in flight before the first LDS write
-            const int sub = lane >> 3, q = lane & 7;
-            float4 mv[8];
-            int4 vv[8];
+            constexpr int LPR = SLAB_STEPS / 4;      // lanes per row
+            constexpr int RPI = WAVE / LPR;          // rows per instruction
+            constexpr int NI = WAVE / RPI;           // instructions per array
+            const int sub = lane / LPR, q = lane % LPR;
+            float4 mv[NI];
+            int4 vv[NI];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int row = 8 * j + sub;
+            for (int j = 0; j < NI; j++) {
+                const int row = RPI * j + sub;
                 const int c = __shfl(cnt, row);      // all lanes take part in the shuffle
                 mv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 vv[j] = make_int4(0, 0, 0, 0);
@@ -570,8 +674,8 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int a = (8 * j + sub) * SLAB_PAD + 4 * q;
+            for (int j = 0; j < NI; j++) {
+                const int a = (RPI * j + sub) * SLAB_PAD + 4 * q;
                 tile_m[a] = mv[j].x; tile_m[a + 1] = mv[j].y;
                 tile_m[a + 2] = mv[j].z; tile_m[a + 3] = mv[j].w;
                 tile_v[a] = vv[j].x; tile_v[a + 1] = vv[j].y;
@@ -580,9 +684,9 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
         } else {
             // generic layout: two rays per instruction, 32 steps each
 #pragma unroll 4
-            for (int j = 0; j < WAVE; j += 2) {
-                const int row = j + (lane >> 5);
-                const int col = lane & 31;
+            for (int j = 0; j < WAVE; j += WAVE / SLAB_STEPS) {
+                const int row = j + lane / SLAB_STEPS;
+                const int col = lane % SLAB_STEPS;
                 const int c = __shfl(cnt, row);
                 float m = 0.0f;
                 int32_t v = 0;
@@ -670,9 +774,13 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
                 }
 #endif
                 if (emit) {
+#ifdef RN_SCATTER_NOATOMIC       // timing experiment only: everything but the atomic
+                    asm volatile("" ::"v"(lin), "v"(val));
+#else
                     if (tail)
                         __hip_atomic_fetch_add(acc_out + lin, val, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
+#endif
                     cursor++;
                     if (cursor < nvalid) vcur = tile_v[lane * SLAB_PAD + cursor];
                 }
@@ -773,7 +881,7 @@ __global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S
         for (int ch = 0; ch < NCH; ch++) {
             const int i = ch * WAVE + lane;
             if (ch * WAVE < count && i < count) {
-                const float d = wv[ch] / wsum;
+                const float d = bp_div(wv[ch], wsum);
                 if (S_new) S_new[(size_t)r * p.M + i] = d;
                 if (d > best) {   // ascending i per lane: keeps the first maximum
                     best = d;
@@ -989,18 +1097,21 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
               int64_t xcd_stride, hipStream_t st) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     const bool fused = ctx->fused_scatter;
+    // measurement knob: dynamic LDS reserved per block only to cap the occupancy
+    const char *lds_env = getenv("RAYNET_HIP_BP_LDS");
+    const size_t bp_lds = lds_env ? (size_t)atoi(lds_env) : 0;
     {
         ProfScope prof(ctx, RN_K_BP, n, st);
 #define RN_BP(NCH_)                                                                         \
     do {                                                                                    \
         if (fused)                                                                          \
             hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, true>), dim3(ray_blocks(n)), \
-                               dim3(BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in,  \
+                               dim3(BLOCK), bp_lds, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in,  \
                                acc_out, msgs_out, xcd_stride);                               \
         else                                                                                \
             hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, false>),                   \
-                               dim3(ray_blocks(n)), dim3(BLOCK), 0, st, ctx->p, n, Sv, vox,   \
-                               rvc, acc_in, msgs_in, acc_out, msgs_out, xcd_stride);         \
+                               dim3(ray_blocks(n)), dim3(BLOCK), bp_lds, st, ctx->p, n, Sv,   \
+                               vox, rvc, acc_in, msgs_in, acc_out, msgs_out, xcd_stride);    \
     } while (0)
         if (nch <= 2) RN_BP(2);
         else if (nch <= 4) RN_BP(4);
@@ -1191,7 +1302,7 @@ int rn_voxel_traversal(rn_ctx *ctx, int32_t n, const float *ray_start, const flo
     if (n == 0) return RN_OK;
     {
         ProfScope prof(ctx, RN_K_TRAVERSE, n, S(stream));
-        hipLaunchKernelGGL((k_traverse<false>), dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream),
+        hipLaunchKernelGGL((k_traverse<false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, S(stream),
                            ctx->p, n, (const int32_t *)nullptr, (const float *)nullptr,
                            (const float *)nullptr, ray_start, ray_end, rvi, rvc);
     }
@@ -1272,7 +1383,7 @@ static int prefix_api(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const flo
     // raynet_fp.py:55-104: traversal (thread per ray), then sweep + mapping (wave per ray)
     {
         ProfScope prof(ctx, RN_K_TRAVERSE, n, st);
-        hipLaunchKernelGGL((k_traverse<false>), dim3(thread_blocks(n)), dim3(BLOCK), 0, st, ctx->p,
+        hipLaunchKernelGGL((k_traverse<false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, st, ctx->p,
                            n, ray_idxs, P_inv, cc, (const float *)nullptr, (const float *)nullptr,
                            rvi, rvc);
     }
@@ -1370,7 +1481,7 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
         if (!fv.v[v]) return fail(ctx, RN_ERR_INVALID, "null feature map for view %d", v);
     {
         ProfScope prof(ctx, RN_K_TRAVERSE, n, S(stream));
-        hipLaunchKernelGGL((k_traverse<true>), dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream),
+        hipLaunchKernelGGL((k_traverse<true>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, S(stream),
                            ctx->p, n, ray_idxs, P_inv, camera_center, (const float *)nullptr,
                            (const float *)nullptr, vox, rvc);
     }

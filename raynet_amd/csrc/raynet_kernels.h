@@ -9,7 +9,7 @@
 //     chunk; the occupancy term is evaluated once per voxel instead of twice;
 //   * the D-deep cost column and the mapped voxel column live in LDS;
 //   * the only serial piece, the 3-D DDA (ray_tracing.pyx:64-199), runs one
-//     thread per ray in its own kernel and hands its list over in HBM.
+//     thread per ray in its own kernel (k_traverse) and hands its list over in HBM.
 // Built with -ffp-contract=off: index maps are bit-exact w.r.t. the oracle.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -277,79 +277,7 @@ __device__ __forceinline__ void softmax_column(int D, int lane, float *Sl) {
 }
 
 // ------------------------------------------------------------------- a3
-// ray_tracing.pyx:64-199, one thread per ray.  emit(i, x, y, z) stores voxel i.
-template <class Emit>
-__device__ __forceinline__ int dda(const Params &p, const float rs[3], const float re[3],
-                                   Emit emit) {
-    const float EPS = 1e-2f;
-    const int g[3] = {p.gx, p.gy, p.gz};
-    float s[3], e[3], bin[3], ray[3];
-    int step[3], cur[3], last[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        s[i] = rs[i] - p.bbox[i];
-        e[i] = re[i] - p.bbox[i];
-        bin[i] = (p.bbox[3 + i] - p.bbox[i]) / g[i];
-        ray[i] = e[i] - s[i];
-        step[i] = ray[i] >= 0 ? 1 : -1;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        s[i] += step[i] * bin[i] * EPS;
-        e[i] -= step[i] * bin[i] * EPS;
-        cur[i] = (int)floorf(s[i] / bin[i]);
-        last[i] = (int)floorf(e[i] / bin[i]);
-    }
-    if (cur[0] < 0 || cur[0] >= g[0] || cur[1] < 0 || cur[1] >= g[1] || cur[2] < 0 ||
-        cur[2] >= g[2])
-        return 0;
-    float tm[3], td[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        tm[i] = FLT_MAX;
-        if (ray[i] != 0) {
-            const float c = cur[i] * bin[i];
-            float b;
-            if (step[i] < 0 && c < s[i])
-                b = c;
-            else
-                b = c + step[i] * bin[i];
-            tm[i] = (b - s[i]) / ray[i];
-        }
-        td[i] = ray[i] != 0 ? step[i] * bin[i] / ray[i] : FLT_MAX;
-    }
-    int cx = cur[0], cy = cur[1], cz = cur[2];
-    float tx = tm[0], ty = tm[1], tz = tm[2];
-    emit(0, cx, cy, cz);
-    int ii = 1;
-    while (!(cx == last[0] && cy == last[1] && cz == last[2]) && ii < p.M) {
-        if (tx < ty) {
-            if (tx < tz) {
-                cx += step[0];
-                if (cx < 0 || cx >= g[0]) return ii;
-                tx += td[0];
-            } else {
-                cz += step[2];
-                if (cz < 0 || cz >= g[2]) return ii;
-                tz += td[2];
-            }
-        } else {
-            if (ty < tz) {
-                cy += step[1];
-                if (cy < 0 || cy >= g[1]) return ii;
-                ty += td[1];
-            } else {
-                cz += step[2];
-                if (cz < 0 || cz >= g[2]) return ii;
-                tz += td[2];
-            }
-        }
-        emit(ii, cx, cy, cz);
-        ii++;
-    }
-    return ii;
-}
-
+// (the DDA itself lives in k_traverse, raynet_hip.hip)
 // voxel list element access: the reference's [M][3] triples or the packed form
 template <bool PACKED>
 __device__ __forceinline__ void load_voxel(const int32_t *__restrict__ row, int i, int &x,
@@ -433,13 +361,27 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
 }
 
 // ------------------------------------------------------------------ a5/a6
+// Value arithmetic of the BP / depth kernels (never index-producing): hardware
+// reciprocal and log2 instead of the ~10-instruction IEEE division and ~15-instruction
+// logf sequences.  Each is within ~2 ulp; the messages' own fp32 conditioning
+// (eps * exp(|m|)) dominates that by far.  expf stays exact: its
+// error would be amplified by o/(1-o) next to the occupancy clamp.
+#ifndef RN_EXACT_BP_MATH
+__device__ __forceinline__ float bp_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float bp_log(float x) {
+    return __builtin_amdgcn_logf(x) * 0.6931471805599453f;    // v_log_f32 is log2
+}
+#else
+__device__ __forceinline__ float bp_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float bp_log(float x) { return logf(x); }
+#endif
 __device__ __forceinline__ float occupancy_to_ray(float acc, float msg) {
     // mrf_bp.cu:12-35
     const float mu = acc - msg;
     const float mx = fmaxf(0.0f, mu);
     const float t1 = expf(0 - mx);
     const float t2 = expf(mu - mx);
-    return clampf(t2 / (t1 + t2), 1e-4f, (float)(1 - 1e-4));
+    return clampf(bp_div(t2, t1 + t2), 1e-4f, (float)(1 - 1e-4));
 }
 
 }  // namespace rn
