@@ -234,23 +234,27 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
                 const int o = __shfl(off[v], src);
                 f[v] = *reinterpret_cast<const float4 *>(fv.v[v] + o + 4 * part);
             }
-            // the only place where multiply-adds may fuse: 4-term partial dot products whose
-            // order already differs from the reference's serial sum (tolerance-tested);
-            // halves the VALU work of the kernel's hottest loop
-            float acc = 0.0f;
+            // sum over view pairs i<j of <f_i, f_j>, as  sum_j <f_0 + ... + f_{j-1}, f_j>  on this
+            // lane's 4 channels: NV-1 packed FMAs and NV-2 packed adds per channel pair instead
+            // of NV(NV-1)/2 products.  This is the only place where multiply-adds may fuse and
+            // where the summation order departs from the reference's serial pair loop (the
+            // kernels are VALU-issue bound; tolerance-tested against the oracle).
+            float acc;
             {
 #pragma clang fp contract(fast)
+                float4 run = f[0];
+                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int i = 0; i < NV; i++) {
-#pragma unroll
-                    for (int j = i + 1; j < NV; j++) {
-                        float d = f[i].x * f[j].x;
-                        d = f[i].y * f[j].y + d;
-                        d = f[i].z * f[j].z + d;
-                        d = f[i].w * f[j].w + d;
-                        acc += d;
+                for (int j = 1; j < NV; j++) {
+                    a4.x = run.x * f[j].x + a4.x;
+                    a4.y = run.y * f[j].y + a4.y;
+                    a4.z = run.z * f[j].z + a4.z;
+                    a4.w = run.w * f[j].w + a4.w;
+                    if (j + 1 < NV) {
+                        run.x += f[j].x; run.y += f[j].y; run.z += f[j].z; run.w += f[j].w;
                     }
                 }
+                acc = (a4.x + a4.y) + (a4.z + a4.w);
             }
 #pragma unroll
             for (int m = 1; m < LPS; m <<= 1) acc += __shfl_xor(acc, m);
@@ -377,10 +381,12 @@ __device__ __forceinline__ float bp_log(float x) { return logf(x); }
 #endif
 __device__ __forceinline__ float occupancy_to_ray(float acc, float msg) {
     // mrf_bp.cu:12-35
+    // t1 = exp(0 - max(0,mu)), t2 = exp(mu - max(0,mu)): one of the two is exp(0) = 1
+    // exactly, the other exp(-|mu|) -- one exponential gives both, bit for bit
     const float mu = acc - msg;
-    const float mx = fmaxf(0.0f, mu);
-    const float t1 = expf(0 - mx);
-    const float t2 = expf(mu - mx);
+    const float e = expf(0 - fabsf(mu));
+    const float t1 = mu > 0.0f ? e : 1.0f;
+    const float t2 = mu > 0.0f ? 1.0f : e;
     return clampf(bp_div(t2, t1 + t2), 1e-4f, (float)(1 - 1e-4));
 }
 
