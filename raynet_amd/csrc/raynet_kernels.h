@@ -231,8 +231,11 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             float4 f[NV];
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                const int o = __shfl(off[v], src);
-                f[v] = *reinterpret_cast<const float4 *>(fv.v[v] + o + 4 * part);
+                // unsigned element offset from a uniform base: one load with a 32-bit
+                // register offset, no 64-bit address arithmetic per lane
+                const unsigned ob = ((unsigned)__shfl(off[v], src) + 4u * (unsigned)part) * 4u;
+                f[v] = *reinterpret_cast<const float4 *>(
+                    reinterpret_cast<const char *>(fv.v[v]) + (size_t)ob);
             }
             // sum over view pairs i<j of <f_i, f_j>, as  sum_j <f_0 + ... + f_{j-1}, f_j>  on this
             // lane's 4 channels: NV-1 packed FMAs and NV-2 packed adds per channel pair instead
