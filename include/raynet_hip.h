@@ -200,10 +200,14 @@ int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, vo
 int rn_acc_reduce_local(rn_ctx *ctx, float *acc_part, float *acc_out, void *stream);
 int rn_acc_add_prior(rn_ctx *ctx, float *acc, float prior, void *stream);
 
-/* depth_map [n] and, when S_new != NULL, the per-ray distribution [n][M] */
+/* depth_map [n] and, when S_new != NULL, the per-ray distribution [n][M].
+ * rays_per_center > 0: the n rays are consecutive groups of rays_per_center rays (one
+ * group per reference image) and group g measures its distances from
+ * camera_center[4*g .. 4*g+3]; 0: one centre for all rays. */
 int rn_scene_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                    const int32_t *rvc, const float *acc, const float *msgs,
-                   const float *camera_center, float *S_new, float *depth_map, void *stream);
+                   const float *camera_center, int32_t rays_per_center, float *S_new,
+                   float *depth_map, void *stream);
 
 /* ---- measurement -------------------------------------------------------- */
 /* Per-launch hipEvent timing on the stream each kernel runs on.  Between

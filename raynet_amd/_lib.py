@@ -85,7 +85,7 @@ SIGNATURES = {
     "rn_acc_combine": [_P, _P, _F, _P, _P],
     "rn_acc_reduce_local": [_P, _P, _P, _P],
     "rn_acc_add_prior": [_P, _P, _F, _P],
-    "rn_scene_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_scene_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "rn_prof_begin": [_P, _I],
     "rn_prof_end": [_P, ctypes.POINTER(_I), _P, _P, _P],
     "rn_timer_start": [_P, _P],

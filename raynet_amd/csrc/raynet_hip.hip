@@ -800,10 +800,11 @@ __global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S
                                                  const float *__restrict__ msgs,
                                                  const float *__restrict__ axes,
                                                  const float *__restrict__ cc, float *S_new,
-                                                 float *depth_map) {
+                                                 float *depth_map, int rays_per_center) {
     int lane;
     const int r = ray_of_wave(n, lane);
     if (r < 0) return;
+    if (rays_per_center > 0 && cc) cc += 4 * (r / rays_per_center);
     const float *Srow = S + (size_t)r * p.M;
     const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
     const float *mrow = msgs + (size_t)r * p.M;
@@ -1138,12 +1139,13 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
 template <bool PACKED, bool CLIP_IN>
 int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
                  const float *acc, const float *msgs, const float *cc, float *S_new,
-                 float *depth_map, hipStream_t st) {
+                 float *depth_map, hipStream_t st, int rays_per_center = 0) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     ProfScope prof(ctx, RN_K_DEPTH, n, st);
 #define RN_DE(NCH_)                                                                             \
     hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
-                       ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, S_new, depth_map)
+                       ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, S_new, depth_map,           \
+                       rays_per_center)
     if (nch <= 2) RN_DE(2);
     else if (nch <= 4) RN_DE(4);
     else if (nch <= 6) RN_DE(6);
@@ -1537,7 +1539,8 @@ int rn_acc_add_prior(rn_ctx *ctx, float *acc, float prior, void *stream) {
 
 int rn_scene_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                    const int32_t *rvc, const float *acc, const float *msgs,
-                   const float *camera_center, float *S_new, float *depth_map, void *stream) {
+                   const float *camera_center, int32_t rays_per_center, float *S_new,
+                   float *depth_map, void *stream) {
     if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc || !msgs || (!S_new && !depth_map) ||
         (depth_map && !camera_center))
@@ -1545,8 +1548,9 @@ int rn_scene_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
     int rc = need_axes(ctx);
     if (rc) return rc;
     if (n == 0) return RN_OK;
+    if (rays_per_center < 0) return fail(ctx, RN_ERR_INVALID, "bad argument");
     return launch_depth<true, false>(ctx, n, Sr, vox, rvc, acc, msgs, camera_center, S_new,
-                                     depth_map, S(stream));
+                                     depth_map, S(stream), rays_per_center);
 }
 
 int rn_prof_begin(rn_ctx *ctx, int32_t capacity) {

@@ -337,9 +337,12 @@ class RayNetForwardPass(ForwardPass):
             cam_host[k, 12 * N + 12:] = center
         cam_dev = ctx.dev(cam_host)
 
-        # K1 prefix once per reference image; columns stay resident
-        per_image = {}
-        orders = {}
+        # K1 prefix once per reference image; the per-ray columns of ALL images live in one
+        # scene-wide buffer each (image k owns rows [k*npad, k*npad + n)), so that every BP
+        # iteration and the depth sweep are single launches over the whole scene: with
+        # per-image launches the tail of each launch (and, on 8 GPUs, its fixed cost) adds up
+        V = len(refs)
+        shards = []
         for k, r in enumerate(refs):
             if self._filter_out_rays:
                 ray_idxs = self.get_valid_rays_per_image(scene, r)
@@ -350,18 +353,28 @@ class RayNetForwardPass(ForwardPass):
                 total = H * W
                 lo, hi = shard_bounds(total, rank, world)
                 ridx = torch.arange(lo, hi, dtype=torch.int32, device=dev)
+            shards.append((ridx, lo, hi, total))
+        npad = max([len(sh[0]) for sh in shards] + [1])
+        npad = (npad + 63) // 64 * 64            # scatter tiles never straddle two images
+        vox_all = torch.empty((V * npad, M), dtype=torch.int32, device=dev)
+        Sr_all = torch.empty((V * npad, M), dtype=torch.float32, device=dev)
+        msgs_all = torch.zeros((V * npad, M), dtype=torch.float32, device=dev)
+        rvc_all = torch.zeros((V * npad,), dtype=torch.int32, device=dev)   # padding rays: count 0
+        per_image = {}
+        orders = {}
+        for k, r in enumerate(refs):
+            ridx, lo, hi, total = shards[k]
             n = len(ridx)
             views = views_of[r]
             images = [scene.get_image(v) for v in views]
             P = cam_dev[k, :12 * N]
             P_inv = cam_dev[k, 12 * N:12 * N + 12]
             center = cam_dev[k, 12 * N + 12:]
-            st = dict(ridx=ridx, n=n, lo=lo, hi=hi, total=total, center=center,
-                      vox=torch.empty((n, M), dtype=torch.int32, device=dev),
-                      rvc=torch.empty((n,), dtype=torch.int32, device=dev),
-                      Sr=torch.empty((n, M), dtype=torch.float32, device=dev),
-                      msgs=torch.zeros((n, M), dtype=torch.float32, device=dev))
-            B = self.rays_batch if self.rays_batch else n
+            row0 = k * npad
+            st = dict(ridx=ridx, n=n, lo=lo, hi=hi, total=total, center=center, row0=row0,
+                      vox=vox_all[row0:row0 + n], rvc=rvc_all[row0:row0 + n],
+                      Sr=Sr_all[row0:row0 + n], msgs=msgs_all[row0:row0 + n])
+            B = self.rays_batch if self.rays_batch else max(n, 1)
             for i in range(0, n, B):
                 order = None
                 if self.sweep_reorder:
@@ -375,17 +388,16 @@ class RayNetForwardPass(ForwardPass):
                                   order=order)
             per_image[r] = st
 
+        n_all = V * npad
+        B_all = self.rays_batch // 64 * 64 if self.rays_batch and self.rays_batch >= 64 else n_all
         for it in range(self.bp_iterations):
-            for r in refs:
-                st = per_image[r]
-                # iteration 0 starts from zero messages (forward_pass.py:613-615); with the
-                # shipped quirk every iteration does (memmap reopened with mode="w+", Q1)
-                first = it == 0 or self.reference_quirks
-                n = st["n"]
-                B = self.rays_batch if self.rays_batch else n
-                for i in range(0, n, B):
-                    ctx.scene_bp_sweep(st["Sr"][i:i + B], st["vox"][i:i + B], st["rvc"][i:i + B],
-                                       acc_in, st["msgs"][i:i + B], acc_part, first_sweep=first)
+            # iteration 0 starts from zero messages (forward_pass.py:613-615); with the
+            # shipped quirk every iteration does (memmap reopened with mode="w+", Q1)
+            first = it == 0 or self.reference_quirks
+            for i in range(0, n_all, B_all):
+                ctx.scene_bp_sweep(Sr_all[i:i + B_all], vox_all[i:i + B_all],
+                                   rvc_all[i:i + B_all], acc_in, msgs_all[i:i + B_all],
+                                   acc_part, first_sweep=first)
             # swap + prior refill of forward_pass.py:676-678; across ranks the prior is
             # added once, after the sum
             if world > 1:
@@ -397,26 +409,43 @@ class RayNetForwardPass(ForwardPass):
             acc_in, acc_next = acc_next, acc_in
         self.accumulator = acc_in
 
-        # depth sweep: all launches and device->host copies are queued first, then the maps
-        # are handed out in order (the reference yields after each image's `.get()`)
-        last = per_image[refs[-1]] if refs else None
+        # depth sweep: one launch over the scene (each image measures from its own camera
+        # centre); maps are copied back asynchronously and handed out in order (the
+        # reference yields after each image's `.get()`)
+        depth_all = torch.zeros((n_all,), dtype=torch.float32, device=dev)
+        if self.reference_quirks and refs:
+            # the loop variable leaks -- every image is decoded with the LAST
+            # image's messages
+            last = per_image[refs[-1]]
+            for r in refs:
+                st = per_image[r]
+                msgs = last["msgs"] if last["n"] == st["n"] else st["msgs"]
+                ctx.scene_depth(st["Sr"], st["vox"], st["rvc"], acc_in, msgs, st["center"], None,
+                                depth_all[st["row0"]:st["row0"] + st["n"]])
+        elif B_all == n_all:
+            centers = cam_dev[:, 12 * N + 12:].contiguous()
+            ctx.scene_depth(Sr_all, vox_all, rvc_all, acc_in, msgs_all, centers, None, depth_all,
+                            rays_per_center=npad)
+        else:
+            for r in refs:
+                st = per_image[r]
+                for i in range(0, st["n"], B_all):
+                    ctx.scene_depth(st["Sr"][i:i + B_all], st["vox"][i:i + B_all],
+                                    st["rvc"][i:i + B_all], acc_in, st["msgs"][i:i + B_all],
+                                    st["center"], None,
+                                    depth_all[st["row0"] + i:st["row0"] + min(i + B_all, st["n"])])
         pending = []
         for r in refs:
             st = per_image[r]
-            msgs = st["msgs"]
-            if self.reference_quirks and last is not None and last["n"] == st["n"]:
-                msgs = last["msgs"]          # the loop variable leaks
-            depth = torch.zeros((st["total"],), dtype=torch.float32, device=dev)
-            n = st["n"]
-            B = self.rays_batch if self.rays_batch else n
-            for i in range(0, n, B):
-                ctx.scene_depth(st["Sr"][i:i + B], st["vox"][i:i + B], st["rvc"][i:i + B],
-                                acc_in, msgs[i:i + B], st["center"], None,
-                                depth[st["lo"] + i:st["lo"] + min(i + B, n)])
             if world > 1:
-                dist.all_reduce(depth, op=dist.ReduceOp.SUM)   # disjoint slices, zeros elsewhere
+                full = torch.zeros((st["total"],), dtype=torch.float32, device=dev)
+                full[st["lo"]:st["hi"]] = depth_all[st["row0"]:st["row0"] + st["n"]]
+                dist.all_reduce(full, op=dist.ReduceOp.SUM)    # disjoint slices, zeros elsewhere
+                src = full
+            else:
+                src = depth_all[st["row0"]:st["row0"] + st["n"]]
             host = torch.empty((st["total"],), dtype=torch.float32, pin_memory=dev.type == "cuda")
-            host.copy_(depth, non_blocking=True)
+            host.copy_(src, non_blocking=True)
             done = torch.cuda.Event() if dev.type == "cuda" else None
             if done is not None:
                 done.record()

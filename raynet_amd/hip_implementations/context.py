@@ -218,7 +218,8 @@ class HipContext(object):
     def acc_add_prior(self, acc, prior):
         self._check(self.lib.rn_acc_add_prior(self._h, _ptr(acc), float(prior), _stream()))
 
-    def scene_depth(self, Sr, vox, rvc, acc, msgs, center, S_new, depth_map):
+    def scene_depth(self, Sr, vox, rvc, acc, msgs, center, S_new, depth_map, rays_per_center=0):
         self._check(self.lib.rn_scene_depth(self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc),
-                                            _ptr(acc), _ptr(msgs), _ptr(center), _ptr(S_new),
-                                            _ptr(depth_map), _stream()))
+                                            _ptr(acc), _ptr(msgs), _ptr(center),
+                                            int(rays_per_center), _ptr(S_new), _ptr(depth_map),
+                                            _stream()))

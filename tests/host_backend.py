@@ -68,11 +68,16 @@ class OracleBackend(object):
         acc_out.copy_(acc_part.sum(0) + np.float32(prior))
         acc_part.zero_()
 
-    def scene_depth(self, Sr, vox, rvc, acc, msgs, center, S_new, depth_map):
+    def scene_depth(self, Sr, vox, rvc, acc, msgs, center, S_new, depth_map, rays_per_center=0):
         rvi = self._unpack(vox)
         Sn = self.o.depth_distribution(Sr.numpy(), rvi, rvc.numpy(), acc.numpy(), msgs.numpy())
         if S_new is not None:
             S_new.numpy()[...] = Sn
         if depth_map is not None:
-            depth_map.numpy()[...] = self.o.depth_from_distribution(Sn, rvi, self._vg,
-                                                                   center.numpy())
+            c = center.numpy().reshape(-1, 4)
+            n = len(Sn)
+            step = rays_per_center if rays_per_center > 0 else max(n, 1)
+            for g, lo in enumerate(range(0, n, step)):
+                hi = min(lo + step, n)
+                depth_map.numpy()[lo:hi] = self.o.depth_from_distribution(
+                    Sn[lo:hi], rvi[lo:hi], self._vg, c[g if rays_per_center > 0 else 0])
