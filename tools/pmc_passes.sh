@@ -14,11 +14,9 @@ for SET in \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum" \
   "FETCH_SIZE" \
   "WRITE_SIZE TCC_EA0_RDREQ_sum" \
-  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_ATOMIC_WITHOUT_RET_sum" \
-  "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum GRBM_GUI_ACTIVE"
+  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_ATOMIC_WITHOUT_RET_sum"
 do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pass$i" -o p -- $CMD > "$OUT/pass$i.log" 2>&1
   echo "pass $i rc=$? : $SET"
 done
-ls -R "$OUT" | head -40
