@@ -173,7 +173,7 @@ def main():
         achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
         traffic = None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if world == 1 and os.path.exists(tpath):     # measured at N=1 launch sizes
             try:
                 traffic = json.load(open(tpath)).get(dominant)
             except Exception:

@@ -434,14 +434,21 @@ class RayNetForwardPass(ForwardPass):
                                     st["rvc"][i:i + B_all], acc_in, st["msgs"][i:i + B_all],
                                     st["center"], None,
                                     depth_all[st["row0"] + i:st["row0"] + min(i + B_all, st["n"])])
+        if world > 1:
+            # every rank writes its slices into a zeroed scene-wide map; ONE all-reduce
+            # (disjoint slices, zeros elsewhere) hands every rank the complete maps
+            offs = np.concatenate([[0], np.cumsum([per_image[r]["total"] for r in refs])])
+            merged = torch.zeros((int(offs[-1]),), dtype=torch.float32, device=dev)
+            for k, r in enumerate(refs):
+                st = per_image[r]
+                merged[int(offs[k]) + st["lo"]:int(offs[k]) + st["hi"]] = \
+                    depth_all[st["row0"]:st["row0"] + st["n"]]
+            dist.all_reduce(merged, op=dist.ReduceOp.SUM)
         pending = []
-        for r in refs:
+        for k, r in enumerate(refs):
             st = per_image[r]
             if world > 1:
-                full = torch.zeros((st["total"],), dtype=torch.float32, device=dev)
-                full[st["lo"]:st["hi"]] = depth_all[st["row0"]:st["row0"] + st["n"]]
-                dist.all_reduce(full, op=dist.ReduceOp.SUM)    # disjoint slices, zeros elsewhere
-                src = full
+                src = merged[int(offs[k]):int(offs[k + 1])]
             else:
                 src = depth_all[st["row0"]:st["row0"] + st["n"]]
             host = torch.empty((st["total"],), dtype=torch.float32, pin_memory=dev.type == "cuda")

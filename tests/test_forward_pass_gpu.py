@@ -187,6 +187,57 @@ def test_full_size_properties(torch):
     assert (np.abs(depths2[0] - depths[0]) > 1e-4).mean() < 1e-3
 
 
+def _config1_scene(torch, device):
+    """BASELINE.json configs[0]: Restrepo mock scene_1 cameras + bbox, 2 views, 16 planes,
+    32^3 voxels, on a 64x36 crop-scaled image."""
+    import os
+    from conftest import GOLDEN
+    from raynet_amd.common.scene import restrepo_cameras_scene
+    from raynet_amd.synthetic import FeatureBank
+    H, W = 36, 64
+    scene = restrepo_cameras_scene(os.path.join(GOLDEN, "restrepo_mock_scene_1"), (H, W),
+                                   scale=W / 1280.0)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    bank = FeatureBank([(torch.randn((H + 12, W + 12, 32), generator=g) * 0.25).to(device)
+                        for _ in range(scene.n_images)])
+    return scene, bank, H, W
+
+
+def test_config1_restrepo_cameras(torch, oracle_mod):
+    scene, bank, H, W = _config1_scene(torch, "cuda")
+    assert scene.n_images == 12
+    assert np.allclose(scene.bbox.ravel(), [-5, -5, -0.7, 5, 5, 1.5])
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    gp = _gp(16, 96, (32, 32, 32), neighbors=1)
+    fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0)
+    depths = list(fp.forward_pass(scene, (0, 3, 1)))
+    o = oracle_mod.Oracle(M=96, D=16, N=2, F=32, H=H, W=W, padding=11, bbox=scene.bbox.ravel(),
+                          grid_shape=(32, 32, 32), threads=oracle_mod.Oracle.max_threads())
+    vg = oracle_mod.voxel_grid_centers(scene.bbox.ravel(), (32, 32, 32))
+    ridx = np.arange(H * W, dtype=np.int32)
+    cams = {}
+    for r in range(3):
+        views = scene.view_indices_with_neighbors(r, 1)
+        cams[r] = (bank.stacked(views).cpu().numpy(),
+                   np.array([scene.get_image(v).camera.P for v in views], np.float32),
+                   scene.get_image(r).camera.P_pinv.astype(np.float32),
+                   scene.get_image(r).camera.center.ravel().astype(np.float32))
+    acc = o.prior(0.05)
+    msgs = {r: np.zeros((H * W, 96), np.float32) for r in range(3)}
+    for it in range(3):
+        out = o.prior(0.05)
+        for r in range(3):
+            f, P, Pi, c = cams[r]
+            rvi, rvc, _ = o.fused_bp(ridx, f, P, Pi, c, vg, acc, msgs[r], out)
+        acc = out
+    assert rvc.max() > 10      # the aerial cameras do see the box
+    assert np.abs(fp.accumulator.cpu().numpy() - acc).max() < 5e-3
+    for r in range(3):
+        f, P, Pi, c = cams[r]
+        _, _, S_new, depth = o.fused_depth(ridx, f, P, Pi, c, vg, acc, msgs[r])
+        assert _depth_close(depths[r], depth.reshape(W, H).T, S_new, W, H) <= 0.02
+
+
 def _rank_main(rank, world, port, out_dir):
     import os
     import sys

@@ -165,3 +165,37 @@ def test_mapping_matches_reference_numpy(oracle_mod, case):
     assert np.allclose(S_new[0, :C], c["li"], rtol=2e-5, atol=1e-7)
     assert np.allclose(S_new[0, :C], c["li_2"], rtol=2e-5, atol=1e-7)
     assert abs(S_new[0, :C].sum() - 1) < 1e-5
+
+
+def test_config1_cpu_plumbing(oracle_mod):
+    """BASELINE.json configs[0] (Restrepo mock cameras, 2 views, 16 planes, 32^3) through the
+    oracle on the CPU: the plumbing case the reference's NumPy path covers."""
+    from conftest import GOLDEN
+    from raynet_amd.common.scene import restrepo_cameras_scene
+    H, W = 36, 64
+    scene = restrepo_cameras_scene(os.path.join(GOLDEN, "restrepo_mock_scene_1"), (H, W),
+                                   scale=W / 1280.0)
+    rng = np.random.default_rng(3)
+    feats = (rng.standard_normal((2, H + 12, W + 12, 32)) * 0.25).astype(np.float32)
+    views = scene.view_indices_with_neighbors(0, 1)
+    assert views == [0, 1]
+    P = np.array([scene.get_image(v).camera.P for v in views], np.float32)
+    cam = scene.get_image(0).camera
+    o = oracle_mod.Oracle(M=96, D=16, N=2, F=32, H=H, W=W, padding=11, bbox=scene.bbox.ravel(),
+                          grid_shape=(32, 32, 32))
+    vg = oracle_mod.voxel_grid_centers(scene.bbox.ravel(), (32, 32, 32))
+    ridx = np.arange(H * W, dtype=np.int32)
+    acc = o.prior(0.05)
+    msgs = np.zeros((H * W, 96), np.float32)
+    for it in range(3):
+        out = o.prior(0.05)
+        rvi, rvc, Sv = o.fused_bp(ridx, feats, P, cam.P_pinv.astype(np.float32),
+                                  cam.center.ravel().astype(np.float32), vg, acc, msgs, out)
+        acc = out
+    _, _, S_new, depth = o.fused_depth(ridx, feats, P, cam.P_pinv.astype(np.float32),
+                                       cam.center.ravel().astype(np.float32), vg, acc, msgs)
+    hit = rvc >= 2
+    assert hit.mean() > 0.5 and np.isfinite(acc).all() and np.isfinite(depth).all()
+    assert np.abs(S_new[hit].sum(1) - 1).max() < 1e-4
+    # the cameras fly ~17 units from the site
+    assert 10 < np.median(depth[hit]) < 25
