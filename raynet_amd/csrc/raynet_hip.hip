@@ -606,7 +606,12 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
     __shared__ float tile_m[WAVE * SLAB_PAD];
     __shared__ int32_t tile_v[WAVE * SLAB_PAD];
     const int lane = threadIdx.x;
-    const int r0 = xcd_block(blockIdx.x, gridDim.x) * WAVE;
+    // one wavefront per (64-ray tile, 32-step chunk): short independent waves keep the
+    // launch's tail and the fixed cost on small shards (8-GPU runs) low
+    const int nchunks = (p.M + SLAB_STEPS - 1) / SLAB_STEPS;
+    const int lb = xcd_block(blockIdx.x, gridDim.x);
+    const int r0 = (lb / nchunks) * WAVE;
+    const int base = (lb % nchunks) * SLAB_STEPS;
     if (xcd_stride) {
         const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
         acc_out += xcc * xcd_stride;
@@ -620,38 +625,9 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
     maxc = uniform(maxc);
-    if (maxc == 0) return;
+    if (base >= maxc) return;
 
-    // dominant axis / direction of the tile: sum over rays of (last voxel - first voxel)
-    int shift = 0, flip = 0;
     {
-        int dx = 0, dy = 0, dz = 0;
-        if (cnt > 0) {
-            int x0, y0, z0, x1, y1, z1;
-            const int32_t *row = vox + (size_t)(r0 + lane) * p.M * (PACKED ? 1 : 3);
-            load_voxel<PACKED>(row, 0, x0, y0, z0);
-            load_voxel<PACKED>(row, cnt - 1, x1, y1, z1);
-            dx = x1 - x0; dy = y1 - y0; dz = z1 - z0;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            dx += __shfl_xor(dx, o);
-            dy += __shfl_xor(dy, o);
-            dz += __shfl_xor(dz, o);
-        }
-        const int ax = abs(dx), ay = abs(dy), az = abs(dz);
-        if (ax >= ay && ax >= az) { shift = 20; flip = dx < 0; }
-        else if (ay >= az) { shift = 10; flip = dy < 0; }
-        else { shift = 0; flip = dz < 0; }
-        shift = uniform(shift);
-        flip = uniform(flip);
-    }
-    auto key_of = [&](int32_t v) {
-        const int c = (v >> shift) & 1023;
-        return flip ? 1023 - c : c;
-    };
-
-    for (int base = 0; base < maxc; base += SLAB_STEPS) {
         if (PACKED && (p.M % SLAB_STEPS) == 0) {
             // rows in: 8 rays per instruction, each lane 4 consecutive steps (16 B); all 16
             // loads of the chunk are in flight before the first LDS write
@@ -712,6 +688,33 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
         const int nvalid = min(max(cnt - base, 0), SLAB_STEPS);
         int cursor = 0;
         int32_t vcur = nvalid > 0 ? tile_v[lane * SLAB_PAD] : 0;
+        // dominant axis / direction of the chunk: sum over rays of (last voxel - first voxel)
+        int shift = 0, flip = 0;
+        {
+            int dx = 0, dy = 0, dz = 0;
+            if (nvalid > 1) {
+                const int32_t vl = tile_v[lane * SLAB_PAD + nvalid - 1];
+                dx = (vl >> 20) - (vcur >> 20);
+                dy = ((vl >> 10) & 1023) - ((vcur >> 10) & 1023);
+                dz = (vl & 1023) - (vcur & 1023);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                dx += __shfl_xor(dx, o);
+                dy += __shfl_xor(dy, o);
+                dz += __shfl_xor(dz, o);
+            }
+            const int ax = abs(dx), ay = abs(dy), az = abs(dz);
+            if (ax >= ay && ax >= az) { shift = 20; flip = dx < 0; }
+            else if (ay >= az) { shift = 10; flip = dy < 0; }
+            else { shift = 0; flip = dz < 0; }
+            shift = uniform(shift);
+            flip = uniform(flip);
+        }
+        auto key_of = [&](int32_t v) {
+            const int c = (v >> shift) & 1023;
+            return flip ? 1023 - c : c;
+        };
         // slab range of this chunk (first / last element of every ray; exact when the
         // rays move monotonically along the tile's axis, which is the normal case)
         int kmin = nvalid > 0 ? key_of(vcur) : 1 << 30;
@@ -1129,8 +1132,11 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
             hipLaunchKernelGGL((k_scatter_tile<PACKED>), dim3((n + WAVE - 1) / WAVE), dim3(BLOCK),
                                0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, xcd_stride);
         else
-            hipLaunchKernelGGL((k_scatter_slab<PACKED>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE),
-                               0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, xcd_stride);
+            hipLaunchKernelGGL((k_scatter_slab<PACKED>),
+                               dim3(((n + WAVE - 1) / WAVE) *
+                                    ((ctx->p.M + SLAB_STEPS - 1) / SLAB_STEPS)),
+                               dim3(WAVE), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
+                               xcd_stride);
         RN_LAUNCH_CHECK(ctx);
     }
     return RN_OK;
