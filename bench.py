@@ -50,15 +50,15 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(kernel, n_rays, voxels, cfg):
+def algorithmic_bytes(kernel, n_rays, voxels, cfg, images=1):
     """Algorithmic HBM bytes of ONE launch.  voxels = sum of the
-    per-ray voxel counts of the rays in the launch."""
+    per-ray voxel counts of the rays in the launch; images = reference images it covers."""
     N, F = cfg["views"], cfg["F"]
     Hf, Wf = cfg["H"] + cfg["padding"] + 1, cfg["W"] + cfg["padding"] + 1
     if kernel == "traverse":      # write packed voxel list + count, read ray index
         return 4 * voxels + 8 * n_rays
     if kernel == "sweep_map":     # N feature maps once; read voxel list, write column
-        return 4 * N * F * Hf * Wf + 8 * voxels + 8 * n_rays
+        return images * 4 * N * F * Hf * Wf + 8 * voxels + 8 * n_rays
     if kernel == "bp":            # Sr, voxel list, msg in, acc gather, msg out
         return 20 * voxels + 4 * n_rays
     if kernel == "scatter":       # msg, voxel list, atomic RMW of the accumulator (8)
@@ -165,7 +165,9 @@ def main():
             # launches are per image shard: voxels of a launch = mean over images with n rays
             vs = vox_by_n.get(n_rays)
             vox = float(np.mean(vs)) if vs else mean_vox * n_rays
-            f["bytes"] += algorithmic_bytes(name, n_rays, vox, cfg_acc)
+            per_image = max(1, min(int(c.numel()) for c in counts.values())) if counts else n_rays
+            f["bytes"] += algorithmic_bytes(name, n_rays, vox, cfg_acc,
+                                            images=max(1, n_rays // per_image))
     dominant = max((k for k in fam if k != "acc"), key=lambda k: fam[k]["ms"], default=None)
     roofline = None
     if dominant:

@@ -185,6 +185,17 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
                      const float *P_inv, const float *camera_center, const int32_t *order,
                      int32_t *vox, int32_t *rvc, float *Sr, void *stream);
 
+/* The same for ALL reference images of a scene in two launches (one grid row per image).
+ * Image g owns rows [g*rows_per_image, g*rows_per_image + n) of vox / rvc / Sr; all images
+ * share ray_idxs [n] and the optional schedule `order` [n].
+ *   cameras        [n_images][12N + 12 + 4] f32: P of the N views, P_inv and camera centre
+ *                  of the reference view (device)
+ *   features_views [n_images][N] device pointers, stored in DEVICE memory */
+int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_per_image,
+                         const int32_t *ray_idxs, const float *const *features_views,
+                         const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
+                         float *Sr, void *stream);
+
 /* acc_part: [rn_acc_copies()][gx][gy][gz] f32, zero before the first sweep of an
  * iteration; messages are scattered into one copy per XCD. */
 int rn_acc_copies(const rn_ctx *ctx);

@@ -118,10 +118,18 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                                                    const float *__restrict__ cc,
                                                    const float *__restrict__ starts,
                                                    const float *__restrict__ ends, int32_t *vox,
-                                                   int32_t *rvc) {
+                                                   int32_t *rvc, int cam_stride,
+                                                   int64_t rows_per_image) {
     __shared__ int32_t tile[WAVE * (TRAV_TILE + 1)];
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * WAVE;
+    if (rows_per_image > 0) {       // blockIdx.y = reference image of a scene-wide launch
+        const int g = blockIdx.y;
+        P_inv += (size_t)g * cam_stride;
+        cc += (size_t)g * cam_stride;
+        vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
+        rvc += (size_t)g * rows_per_image;
+    }
     const int r = r0 + lane;
     const bool live = r < n;
     float s[3] = {0.f, 0.f, 0.f}, e[3] = {0.f, 0.f, 0.f};
@@ -247,7 +255,18 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
     const float *__restrict__ S_in, const float *__restrict__ axes_g,
     const int32_t *__restrict__ vox, const int32_t *__restrict__ rvc, float *S_planes,
     float *S_voxel, float *depth_from_planes, float *points,
-    const int32_t *__restrict__ order) {
+    const int32_t *__restrict__ order, const float *const *__restrict__ fv_table, int cam_stride,
+    int64_t rows_per_image) {
+    if (rows_per_image > 0) {       // blockIdx.y = reference image of a scene-wide launch
+        const int g = blockIdx.y;
+        P += (size_t)g * cam_stride;
+        P_inv += (size_t)g * cam_stride;
+        cc += (size_t)g * cam_stride;
+        fv_table += (size_t)g * p.N;
+        vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
+        rvc += (size_t)g * rows_per_image;
+        S_voxel += (size_t)g * rows_per_image * p.M;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int naxes = p.gx + p.gy + p.gz;
     float *axes = smem;
@@ -278,9 +297,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
         for (int k = lane; k < p.D; k += WAVE) Sl[k] = S_in[(size_t)r * p.D + k];
     } else {
         if (SIM == 1)
-            sweep_generic(p, fv, P, s, e, lane, Sl);
+            sweep_generic(p, fv, fv_table, P, s, e, lane, Sl);
         else
-            sweep_coop<NV, LPS>(p, fv, P, s, e, lane, Sl);
+            sweep_coop<NV, LPS>(p, fv, fv_table, P, s, e, lane, Sl);
         wave_sync();
         softmax_column(p.D, lane, Sl);
     }
@@ -1062,15 +1081,21 @@ struct SweepArgs {
     const int32_t *vox, *rvc;
     float *S_planes, *S_voxel, *depth_from_planes, *points;
     const int32_t *order = nullptr;
+    // scene-wide launch (rn_scene_prepare_all): one grid row per reference image
+    const float *const *fv_table = nullptr;
+    int cam_stride = 0;
+    int64_t rows_per_image = 0;
+    int n_images = 1;
 };
 
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
 void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
-    ProfScope prof(ctx, RN_K_SWEEP_MAP, a.n, st);
-    hipLaunchKernelGGL((k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>), dim3(ray_blocks(a.n)),
-                       dim3(BLOCK), sweep_lds(ctx->p), st, ctx->p, a.n, a.ray_idxs, a.fv, a.P,
-                       a.P_inv, a.cc, a.starts, a.ends, a.S_in, ctx->axes, a.vox, a.rvc,
-                       a.S_planes, a.S_voxel, a.depth_from_planes, a.points, a.order);
+    ProfScope prof(ctx, RN_K_SWEEP_MAP, a.n * a.n_images, st);
+    hipLaunchKernelGGL((k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>),
+                       dim3(ray_blocks(a.n), a.n_images), dim3(BLOCK), sweep_lds(ctx->p), st,
+                       ctx->p, a.n, a.ray_idxs, a.fv, a.P, a.P_inv, a.cc, a.starts, a.ends, a.S_in,
+                       ctx->axes, a.vox, a.rvc, a.S_planes, a.S_voxel, a.depth_from_planes,
+                       a.points, a.order, a.fv_table, a.cam_stride, a.rows_per_image);
 }
 
 // pick the plane-sweep flavour: cooperative for F=32 and 2..9 views, generic otherwise
@@ -1312,7 +1337,7 @@ int rn_voxel_traversal(rn_ctx *ctx, int32_t n, const float *ray_start, const flo
         ProfScope prof(ctx, RN_K_TRAVERSE, n, S(stream));
         hipLaunchKernelGGL((k_traverse<false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, S(stream),
                            ctx->p, n, (const int32_t *)nullptr, (const float *)nullptr,
-                           (const float *)nullptr, ray_start, ray_end, rvi, rvc);
+                           (const float *)nullptr, ray_start, ray_end, rvi, rvc, 0, (int64_t)0);
     }
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
@@ -1393,7 +1418,7 @@ static int prefix_api(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const flo
         ProfScope prof(ctx, RN_K_TRAVERSE, n, st);
         hipLaunchKernelGGL((k_traverse<false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, st, ctx->p,
                            n, ray_idxs, P_inv, cc, (const float *)nullptr, (const float *)nullptr,
-                           rvi, rvc);
+                           rvi, rvc, 0, (int64_t)0);
     }
     RN_LAUNCH_CHECK(ctx);
     SweepArgs a{n, ray_idxs, stacked_views(ctx->p, features), P, P_inv, cc, nullptr, nullptr,
@@ -1491,12 +1516,44 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
         ProfScope prof(ctx, RN_K_TRAVERSE, n, S(stream));
         hipLaunchKernelGGL((k_traverse<true>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, S(stream),
                            ctx->p, n, ray_idxs, P_inv, camera_center, (const float *)nullptr,
-                           (const float *)nullptr, vox, rvc);
+                           (const float *)nullptr, vox, rvc, 0, (int64_t)0);
     }
     RN_LAUNCH_CHECK(ctx);
     SweepArgs a{n, ray_idxs, fv, P, P_inv, camera_center, nullptr, nullptr, nullptr, vox, rvc,
                 nullptr, Sr, nullptr, nullptr};
     a.order = order;
+    launch_sweep<2, true>(ctx, a, true, S(stream));
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_per_image,
+                         const int32_t *ray_idxs, const float *const *features_views,
+                         const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
+                         float *Sr, void *stream) {
+    if (!ctx || n_images < 1 || n < 0 || rows_per_image < n || !ray_idxs || !features_views ||
+        !cameras || !vox || !rvc || !Sr)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    int rc = need_axes(ctx);
+    if (rc) return rc;
+    if (n == 0) return RN_OK;
+    const int N = ctx->p.N;
+    const int cam_stride = 12 * N + 12 + 4;
+    const float *P = cameras, *P_inv = cameras + 12 * N, *cc = cameras + 12 * N + 12;
+    {
+        ProfScope prof(ctx, RN_K_TRAVERSE, n * n_images, S(stream));
+        hipLaunchKernelGGL((k_traverse<true>), dim3((n + WAVE - 1) / WAVE, n_images), dim3(WAVE), 0,
+                           S(stream), ctx->p, n, ray_idxs, P_inv, cc, (const float *)nullptr,
+                           (const float *)nullptr, vox, rvc, cam_stride, rows_per_image);
+    }
+    RN_LAUNCH_CHECK(ctx);
+    SweepArgs a{n, ray_idxs, FeatureViews{}, P, P_inv, cc, nullptr, nullptr, nullptr, vox, rvc,
+                nullptr, Sr, nullptr, nullptr};
+    a.order = order;
+    a.fv_table = features_views;
+    a.cam_stride = cam_stride;
+    a.rows_per_image = rows_per_image;
+    a.n_images = n_images;
     launch_sweep<2, true>(ctx, a, true, S(stream));
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;

@@ -179,6 +179,7 @@ __device__ __forceinline__ void plane_point(const float s[3], const float e[3], 
 // the reference's order (pairs i<j, then f), so it tracks the oracle to the
 // last bit before expf.  Any N, any F.  Writes raw pair sums / pairs to Sl[D].
 __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureViews &fv,
+                                              const float *const *__restrict__ tbl,
                                               const float *__restrict__ P, const float s[3],
                                               const float e[3], int lane, float *Sl) {
     const int pairs = (p.N * (p.N - 1)) / 2;
@@ -189,9 +190,10 @@ __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureView
             plane_point(s, e, k, p.D, point);
             float acc = 0.0f;
             for (int i = 0; i < p.N; i++) {
-                const float *fi = fv.v[i] + feature_offset(p, P + 12 * i, point);
+                const float *fi = (tbl ? tbl[i] : fv.v[i]) + feature_offset(p, P + 12 * i, point);
                 for (int j = i + 1; j < p.N; j++) {
-                    const float *fj = fv.v[j] + feature_offset(p, P + 12 * j, point);
+                    const float *fj =
+                        (tbl ? tbl[j] : fv.v[j]) + feature_offset(p, P + 12 * j, point);
                     float dot = 0.0f;
                     for (int f = 0; f < p.F; f++) dot += fi[f] * fj[f];
                     acc += dot;
@@ -208,9 +210,13 @@ __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureView
 // LPS partial sums are folded with an xor butterfly.
 template <int NV, int LPS>
 __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &fv,
+                                           const float *const *__restrict__ tbl,
                                            const float *__restrict__ P, const float s[3],
                                            const float e[3], int lane, float *Sl) {
     constexpr int SPL = WAVE / LPS;       // planes per load instruction
+    const float *vbase[NV];               // uniform per-view bases (kernel argument or table)
+#pragma unroll
+    for (int v = 0; v < NV; v++) vbase[v] = tbl ? tbl[v] : fv.v[v];
     const int sub = lane / LPS;           // which plane of the group
     const int part = lane % LPS;          // which float4 of the vector
     const int pairs = (NV * (NV - 1)) / 2;
@@ -235,7 +241,7 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
                 // register offset, no 64-bit address arithmetic per lane
                 const unsigned ob = ((unsigned)__shfl(off[v], src) + 4u * (unsigned)part) * 4u;
                 f[v] = *reinterpret_cast<const float4 *>(
-                    reinterpret_cast<const char *>(fv.v[v]) + (size_t)ob);
+                    reinterpret_cast<const char *>(vbase[v]) + (size_t)ob);
             }
             // sum over view pairs i<j of <f_i, f_j>, as  sum_j <f_0 + ... + f_{j-1}, f_j>  on this
             // lane's 4 channels: NV-1 packed FMAs and NV-2 packed adds per channel pair instead

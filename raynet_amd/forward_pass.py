@@ -365,28 +365,46 @@ class RayNetForwardPass(ForwardPass):
         for k, r in enumerate(refs):
             ridx, lo, hi, total = shards[k]
             n = len(ridx)
-            views = views_of[r]
-            images = [scene.get_image(v) for v in views]
-            P = cam_dev[k, :12 * N]
-            P_inv = cam_dev[k, 12 * N:12 * N + 12]
-            center = cam_dev[k, 12 * N + 12:]
             row0 = k * npad
-            st = dict(ridx=ridx, n=n, lo=lo, hi=hi, total=total, center=center, row0=row0,
-                      vox=vox_all[row0:row0 + n], rvc=rvc_all[row0:row0 + n],
-                      Sr=Sr_all[row0:row0 + n], msgs=msgs_all[row0:row0 + n])
-            B = self.rays_batch if self.rays_batch else max(n, 1)
-            for i in range(0, n, B):
-                order = None
-                if self.sweep_reorder:
-                    mode = sweep_direction(H, W, images)
-                    key = (mode, lo + i, min(lo + i + B, hi))
-                    if mode == "rows" and (self._filter_out_rays or key not in orders):
-                        orders[key] = row_major_order(ridx[i:i + B], H, W)
-                    order = orders.get(key) if mode == "rows" else None
-                ctx.scene_prepare(ridx[i:i + B], [bank[v] for v in views], P, P_inv, center,
-                                  st["vox"][i:i + B], st["rvc"][i:i + B], st["Sr"][i:i + B],
+            per_image[r] = dict(ridx=ridx, n=n, lo=lo, hi=hi, total=total, row0=row0,
+                                center=cam_dev[k, 12 * N + 12:],
+                                vox=vox_all[row0:row0 + n], rvc=rvc_all[row0:row0 + n],
+                                Sr=Sr_all[row0:row0 + n], msgs=msgs_all[row0:row0 + n])
+
+        def order_for(ridx_slice, lo_i, hi_i, images):
+            if not self.sweep_reorder or sweep_direction(H, W, images) != "rows":
+                return None
+            key = (lo_i, hi_i)
+            if self._filter_out_rays or key not in orders:
+                orders[key] = row_major_order(ridx_slice, H, W)
+            return orders[key]
+
+        whole = not self._filter_out_rays and not self.rays_batch and V > 0
+        if whole:
+            modes = {sweep_direction(H, W, [scene.get_image(v) for v in views_of[r]]) for r in refs}
+            whole = len(modes) == 1 or not self.sweep_reorder
+        if whole and hasattr(ctx, "scene_prepare_all"):
+            # every image traverses / sweeps the same ray list: two launches for the scene
+            ridx, lo, hi, total = shards[0]
+            order = order_for(ridx, lo, hi, [scene.get_image(v) for v in views_of[refs[0]]])
+            table = torch.tensor([[bank[v].data_ptr() for v in views_of[r]] for r in refs],
+                                 dtype=torch.int64).to(dev)
+            ctx.scene_prepare_all(V, npad, ridx, table, cam_dev, vox_all, rvc_all, Sr_all,
                                   order=order)
-            per_image[r] = st
+        else:
+            for k, r in enumerate(refs):
+                st = per_image[r]
+                ridx, lo, n = st["ridx"], st["lo"], st["n"]
+                views = views_of[r]
+                images = [scene.get_image(v) for v in views]
+                P = cam_dev[k, :12 * N]
+                P_inv = cam_dev[k, 12 * N:12 * N + 12]
+                B = self.rays_batch if self.rays_batch else max(n, 1)
+                for i in range(0, n, B):
+                    order = order_for(ridx[i:i + B], lo + i, min(lo + i + B, st["hi"]), images)
+                    ctx.scene_prepare(ridx[i:i + B], [bank[v] for v in views], P, P_inv,
+                                      st["center"], st["vox"][i:i + B], st["rvc"][i:i + B],
+                                      st["Sr"][i:i + B], order=order)
 
         n_all = V * npad
         B_all = self.rays_batch // 64 * 64 if self.rays_batch and self.rays_batch >= 64 else n_all

@@ -203,6 +203,20 @@ class HipContext(object):
                                               _ptr(P_inv), _ptr(center), _ptr(order), _ptr(vox),
                                               _ptr(rvc), _ptr(Sr), _stream()))
 
+    def scene_prepare_all(self, n_images, rows_per_image, ray_idxs, feature_table, cameras, vox,
+                          rvc, Sr, order=None):
+        """feature_table: int64 CUDA tensor [n_images, N] of device pointers;
+        cameras: float32 CUDA tensor [n_images, 12N + 16]."""
+        assert feature_table.dtype == torch.int64 and feature_table.is_contiguous()
+        assert tuple(feature_table.shape) == (n_images, self.N)
+        assert cameras.dtype == torch.float32 and cameras.is_contiguous()
+        assert tuple(cameras.shape) == (n_images, 12 * self.N + 16)
+        assert order is None or (order.dtype == torch.int32 and len(order) == len(ray_idxs))
+        self._check(self.lib.rn_scene_prepare_all(
+            self._h, int(n_images), len(ray_idxs), int(rows_per_image), _ptr(ray_idxs),
+            _ptr(feature_table), _ptr(cameras), _ptr(order), _ptr(vox), _ptr(rvc), _ptr(Sr),
+            _stream()))
+
     def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False):
         self._check(self.lib.rn_scene_bp_sweep(self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc),
                                                _ptr(acc_in), _ptr(msgs), _ptr(acc_part),
