@@ -238,6 +238,44 @@ int rn_prof_begin(rn_ctx *ctx, int32_t capacity);
 int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *n_rays_host,
                 float *ms_host);
 
+/* ---- differentiable MRF block (training) --------------
+ * The reference builds this block from TensorFlow ops and lets autodiff
+ * differentiate it (raynet/tf_implementations/forward_backward_pass.py:194-246,
+ * raynet/mrf/mrf_tf.py:1-236); these entry points are the forward on a column that the
+ * framework has already clipped + renormalised (so that step stays differentiable there)
+ * and the analytic reverse-mode derivative of one BP sweep / of the depth distribution.
+ * rvi is the [n][M][3] traversal output (K5 layout). */
+
+/* left plane index and interpolation weights (c1, c2), [n][M] each, of the
+ * planes->voxels mapping (planes_voxels_mapping.cu:48-84): S_voxel[i] is
+ * normalise_i(c1[i] S[left[i]] + c2[i] S[left[i]+1]) */
+int rn_plane_weights(rn_ctx *ctx, int32_t n, const int32_t *rvi, const int32_t *rvc,
+                     const float *ray_start, const float *ray_end, int32_t *left, float *c1,
+                     float *c2, void *stream);
+
+/* rn_bp_sweep / rn_depth_estimation without their internal clip_and_renorm */
+int rn_train_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *rvi,
+                      const int32_t *rvc, const float *acc_in, const float *msgs_in,
+                      float *acc_out, float *msgs_out, void *stream);
+int rn_train_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *rvi,
+                   const int32_t *rvc, const float *acc, const float *msgs, float *S_new,
+                   void *stream);
+
+/* Backward of rn_train_bp_sweep.  g_msgs_out [n][M]: gradient w.r.t. the new messages
+ * from their direct use by the next sweep; g_acc_out [G] (may be NULL): gradient w.r.t.
+ * acc_out.  Results: g_Sr [n][M] += , g_acc_in [G] += (atomic; caller zeroes),
+ * g_msgs_in [n][M] = . */
+int rn_train_bp_sweep_bwd(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *rvi,
+                          const int32_t *rvc, const float *acc_in, const float *msgs_in,
+                          const float *g_msgs_out, const float *g_acc_out, float *g_Sr,
+                          float *g_acc_in, float *g_msgs_in, void *stream);
+
+/* Backward of rn_train_depth for g_S_new [n][M]; same output conventions. */
+int rn_train_depth_bwd(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *rvi,
+                       const int32_t *rvc, const float *acc, const float *msgs,
+                       const float *g_S_new, float *g_Sr, float *g_acc, float *g_msgs,
+                       void *stream);
+
 /* hipEvent pair on `stream`; rn_timer_stop returns elapsed milliseconds after
  * synchronising on the stop event (bench.py's per-kernel timing). */
 int rn_timer_start(rn_ctx *ctx, void *stream);

@@ -89,6 +89,11 @@ SIGNATURES = {
     "rn_scene_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "rn_prof_begin": [_P, _I],
     "rn_prof_end": [_P, ctypes.POINTER(_I), _P, _P, _P],
+    "rn_plane_weights": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_train_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_train_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "rn_train_bp_sweep_bwd": [_P, _I] + [_P] * 11,
+    "rn_train_depth_bwd": [_P, _I] + [_P] * 10,
     "rn_timer_start": [_P, _P],
     "rn_timer_stop": [_P, _P, ctypes.POINTER(_F)],
 }

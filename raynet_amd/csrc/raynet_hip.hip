@@ -1682,3 +1682,6 @@ int rn_timer_stop(rn_ctx *ctx, void *stream, float *ms_out) {
 }
 
 }  // extern "C"
+
+// training (differentiable) entry points, SURVEY.md 8f row 2
+#include "raynet_train.inl"

@@ -105,6 +105,33 @@ class HipContext(object):
         self._check(self.lib.rn_timer_stop(self._h, _stream(), ctypes.byref(ms)))
         return float(ms.value)
 
+    # ---- differentiable MRF block (training) -----------------------------------------
+    def plane_weights(self, rvi, rvc, starts, ends, left, c1, c2):
+        self._check(self.lib.rn_plane_weights(self._h, len(rvc), _ptr(rvi), _ptr(rvc), _ptr(starts),
+                                              _ptr(ends), _ptr(left), _ptr(c1), _ptr(c2),
+                                              _stream()))
+
+    def train_bp_sweep(self, Sr, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out):
+        self._check(self.lib.rn_train_bp_sweep(self._h, len(rvc), _ptr(Sr), _ptr(rvi), _ptr(rvc),
+                                               _ptr(acc_in), _ptr(msgs_in), _ptr(acc_out),
+                                               _ptr(msgs_out), _stream()))
+
+    def train_depth(self, Sr, rvi, rvc, acc, msgs, S_new):
+        self._check(self.lib.rn_train_depth(self._h, len(rvc), _ptr(Sr), _ptr(rvi), _ptr(rvc),
+                                            _ptr(acc), _ptr(msgs), _ptr(S_new), _stream()))
+
+    def train_bp_sweep_bwd(self, Sr, rvi, rvc, acc_in, msgs_in, g_msgs_out, g_acc_out, g_Sr,
+                           g_acc_in, g_msgs_in):
+        self._check(self.lib.rn_train_bp_sweep_bwd(
+            self._h, len(rvc), _ptr(Sr), _ptr(rvi), _ptr(rvc), _ptr(acc_in), _ptr(msgs_in),
+            _ptr(g_msgs_out), _ptr(g_acc_out), _ptr(g_Sr), _ptr(g_acc_in), _ptr(g_msgs_in),
+            _stream()))
+
+    def train_depth_bwd(self, Sr, rvi, rvc, acc, msgs, g_S_new, g_Sr, g_acc, g_msgs):
+        self._check(self.lib.rn_train_depth_bwd(
+            self._h, len(rvc), _ptr(Sr), _ptr(rvi), _ptr(rvc), _ptr(acc), _ptr(msgs),
+            _ptr(g_S_new), _ptr(g_Sr), _ptr(g_acc), _ptr(g_msgs), _stream()))
+
     KERNEL_NAMES = {1: "traverse", 2: "sweep_map", 3: "bp", 4: "depth", 5: "acc", 6: "other", 7: "scatter"}
 
     def prof_begin(self, capacity=4096):

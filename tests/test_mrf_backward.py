@@ -1,0 +1,84 @@
+"""the analytic backward of mapping -> clip/renorm -> BP -> depth.
+CPU part: the float64 statement (oracle/mrf_backward.py) against central finite
+differences of its own forward, and its forward against the fp32 C oracle."""
+import numpy as np
+import pytest
+
+
+def make_problem(oracle_mod, n=24, D=12, M=40, grid=(12, 12, 12), seed=0):
+    rng = np.random.default_rng(seed)
+    bbox = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    o = oracle_mod.Oracle(M=M, D=D, N=2, F=4, H=4, W=4, padding=3, bbox=bbox, grid_shape=grid)
+    vg = oracle_mod.voxel_grid_centers(bbox, grid)
+    # rays converging on a region so that they share voxels (coupled through the accumulator)
+    starts = np.zeros((n, 3), np.float32)
+    ends = np.zeros((n, 3), np.float32)
+    for r in range(n):
+        a = rng.integers(0, 3)
+        p = rng.random(3) * 1.2 - 0.6
+        q = rng.random(3) * 0.6 - 0.3
+        p[a], q[a] = -1.0, 1.0
+        starts[r], ends[r] = p, q
+    starts[0] = ends[0] = 5.0                # outside the box: count 0 (skipped ray)
+    rvi, rvc = o.traversal(starts, ends)
+    S = rng.random((n, D)) ** 3 + 0.02
+    S /= S.sum(1, keepdims=True)
+    planes = o.plane_indices(vg, rvi, rvc, starts, ends)
+    return o, vg, starts, ends, rvi, rvc, S, planes
+
+
+def test_float64_forward_matches_fp32_oracle(oracle_mod):
+    from oracle import mrf_backward as mb
+    o, vg, starts, ends, rvi, rvc, S, planes = make_problem(oracle_mod)
+    out = mb.forward(S, vg, rvi, rvc, starts, ends, o.grid_shape, planes=planes)
+    Sv = o.planes_to_voxels(vg, rvi, rvc, starts, ends, S.astype(np.float32))
+    msgs = np.zeros_like(Sv)
+    acc, msgs = o.belief_propagation(Sv, rvi, rvc, msgs, gamma=0.05, bp_iterations=3)
+    ref = o.depth_distribution(Sv, rvi, rvc, acc, msgs)
+    assert np.abs(out - ref).max() < 5e-5
+    assert np.all(out[rvc <= 1] == 0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_analytic_backward_matches_finite_differences(oracle_mod, seed):
+    from oracle import mrf_backward as mb
+    o, vg, starts, ends, rvi, rvc, S, planes = make_problem(oracle_mod, seed=seed)
+    rng = np.random.default_rng(100 + seed)
+    G = rng.standard_normal((len(S), rvi.shape[1]))
+    args = (vg, rvi, rvc, starts, ends, o.grid_shape)
+    dS = mb.backward(G, S, *args, planes=planes)
+    assert np.all(dS[rvc <= 1] == 0)
+
+    def loss(Sx):
+        return (G * mb.forward(Sx, *args, planes=planes)).sum()
+
+    h = 1e-6
+    worst = 0.0
+    checked = 0
+    for r in range(len(S)):
+        if rvc[r] <= 1:
+            continue
+        for k in rng.choice(S.shape[1], 4, replace=False):
+            Sp, Sm = S.copy(), S.copy()
+            Sp[r, k] += h
+            Sm[r, k] -= h
+            fd = (loss(Sp) - loss(Sm)) / (2 * h)
+            err = abs(fd - dS[r, k]) / max(1e-6, abs(fd), abs(dS[r, k]))
+            worst = max(worst, err)
+            checked += 1
+    assert checked > 50 and worst < 1e-4, worst
+
+
+def test_prior_gradient_matches_finite_differences(oracle_mod):
+    from oracle import mrf_backward as mb
+    o, vg, starts, ends, rvi, rvc, S, planes = make_problem(oracle_mod, seed=3)
+    rng = np.random.default_rng(7)
+    G = rng.standard_normal((len(S), rvi.shape[1]))
+    args = (vg, rvi, rvc, starts, ends, o.grid_shape)
+    gamma = 0.05
+    _, prior_bar = mb.backward(G, S, *args, gamma=gamma, planes=planes, with_prior=True)
+    dgamma = prior_bar * (1.0 / gamma + 1.0 / (1.0 - gamma))
+    h = 1e-7
+    fd = ((G * mb.forward(S, *args, gamma=gamma + h, planes=planes)).sum() -
+          (G * mb.forward(S, *args, gamma=gamma - h, planes=planes)).sum()) / (2 * h)
+    assert abs(fd - dgamma) < 1e-5 * max(1.0, abs(fd)), (fd, dgamma)
