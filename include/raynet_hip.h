@@ -200,10 +200,15 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
  * iteration; messages are scattered into one copy per XCD. */
 int rn_acc_copies(const rn_ctx *ctx);
 /* first_sweep != 0: the messages are taken as zero and `msgs` is only written, so it
- * needs no zero-fill (the reference zero-fills for iteration 0, forward_pass.py:613-615). */
+ * needs no zero-fill (the reference zero-fills for iteration 0, forward_pass.py:613-615).
+ * row_layout says how consecutive rows relate in the image, which only selects the
+ * accumulator-scatter kernel (any value is correct for any input, it is a speed hint):
+ * RN_ROWS_LINEAR  -- consecutive rows run along an image column / row (ray-index order);
+ * RN_ROWS_PATCHES -- every 256 consecutive rows are a compact pixel patch (e.g. 16x16). */
+typedef enum { RN_ROWS_LINEAR = 0, RN_ROWS_PATCHES = 1 } rn_row_layout;
 int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                       const int32_t *rvc, const float *acc_in, float *msgs, float *acc_part,
-                      int32_t first_sweep, void *stream);
+                      int32_t first_sweep, int32_t row_layout, void *stream);
 /* acc_out = prior + sum over copies (+ optionally `extra`, e.g. nothing or a
  * peer's partial); the copies are zeroed for the next iteration. */
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream);

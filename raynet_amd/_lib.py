@@ -30,7 +30,8 @@ class RaynetHipError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "raynet_hip.hip"), os.path.join(CSRC, "raynet_kernels.h"), HEADER]
+    srcs = [os.path.join(CSRC, "raynet_hip.hip"), os.path.join(CSRC, "raynet_kernels.h"),
+            os.path.join(CSRC, "raynet_train.inl"), HEADER]
     if not force and os.path.exists(LIB_PATH) and \
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -82,7 +83,7 @@ SIGNATURES = {
     "rn_scene_prepare": [_P, _I, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P],
     "rn_scene_prepare_all": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "rn_acc_copies": [_P],
-    "rn_scene_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
+    "rn_scene_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "rn_acc_combine": [_P, _P, _F, _P, _P],
     "rn_acc_reduce_local": [_P, _P, _P, _P],
     "rn_acc_add_prior": [_P, _P, _F, _P],

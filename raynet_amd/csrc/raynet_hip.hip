@@ -812,6 +812,179 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
     }
 }
 
+// ------------------------------------------------- accumulator scatter, LDS box
+// A tile of BOX_RAYS neighbouring rays x BOX_STEPS steps covers a compact block of the grid
+// in which every voxel is hit by ~10-20 of the tile's rays (ray spacing << voxel size).
+// The tile's messages are therefore summed in a dense LDS image of its bounding box
+// in DOUBLE (measured, tools/lds_atomic_bench.hip: ds_add_f64 runs at ~1.7 T lane-ops/s,
+// ds_add_f32 at 0.2 T/s whatever the addresses; the sums also become order-independent to
+// ~1e-16, i.e. the accumulator is reproducible run to run) and the box is flushed once,
+// z-fastest, so that the global atomics of one instruction fall into a few 64-byte segments
+// and there is one per DISTINCT voxel of the tile instead of one per (ray, voxel).
+// The box comes from the first / last voxel of every ray segment (a DDA list is monotone
+// along each axis); an element outside it -- arbitrary caller-made lists -- or a tile whose
+// box exceeds the LDS budget goes straight to the global atomic: always correct.
+#ifndef RN_BOX_STEPS
+#define RN_BOX_STEPS 16
+#endif
+#ifndef RN_BOX_RAYS
+#define RN_BOX_RAYS 256
+#endif
+#ifndef RN_BOX_CAP
+#define RN_BOX_CAP 2048
+#endif
+#ifndef RN_BOX_NB
+#define RN_BOX_NB 16
+#endif
+constexpr int BOX_NB = RN_BOX_NB;
+constexpr int BOX_STEPS = RN_BOX_STEPS;
+constexpr int BOX_RAYS = RN_BOX_RAYS;
+constexpr int BOX_CAP = RN_BOX_CAP;      // voxels (doubles of LDS) per tile
+template <bool PACKED>
+__global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
+                                                       const float *__restrict__ msgs,
+                                                       const int32_t *__restrict__ vox,
+                                                       const int32_t *__restrict__ rvc,
+                                                       float *acc_out, int64_t xcd_stride) {
+    __shared__ double box[BOX_CAP];
+    __shared__ int red[6 * WAVES_PER_BLOCK];
+    __shared__ int cnts[BOX_RAYS];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
+    const int nchunks = (p.M + BOX_STEPS - 1) / BOX_STEPS;
+    const int lb = xcd_block(blockIdx.x, gridDim.x);
+    const int r0 = (lb / nchunks) * BOX_RAYS;
+    const int s0 = (lb % nchunks) * BOX_STEPS;
+    if (xcd_stride) {
+        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
+        acc_out += xcc * xcd_stride;
+    }
+    const size_t vstride = PACKED ? 1 : 3;
+    // ---- bounding box of the tile's segments
+    int lo0 = 1 << 30, lo1 = 1 << 30, lo2 = 1 << 30, hi0 = -1, hi1 = -1, hi2 = -1;
+    for (int j = tid; j < BOX_RAYS; j += BLOCK) {
+        const int r = r0 + j;
+        int cnt = r < n ? min(rvc[r], p.M) : 0;
+        if (cnt <= 1) cnt = 0;        // such rays send no message (mrf_np.py:300)
+        cnts[j] = cnt;
+        if (s0 < cnt) {
+            const int32_t *vrow = vox + (size_t)r * p.M * vstride;
+            int x, y, z;
+            load_voxel<PACKED>(vrow, s0, x, y, z);
+            lo0 = min(lo0, x); hi0 = max(hi0, x);
+            lo1 = min(lo1, y); hi1 = max(hi1, y);
+            lo2 = min(lo2, z); hi2 = max(hi2, z);
+            load_voxel<PACKED>(vrow, min(cnt, s0 + BOX_STEPS) - 1, x, y, z);
+            lo0 = min(lo0, x); hi0 = max(hi0, x);
+            lo1 = min(lo1, y); hi1 = max(hi1, y);
+            lo2 = min(lo2, z); hi2 = max(hi2, z);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo0 = min(lo0, __shfl_xor(lo0, o)); hi0 = max(hi0, __shfl_xor(hi0, o));
+        lo1 = min(lo1, __shfl_xor(lo1, o)); hi1 = max(hi1, __shfl_xor(hi1, o));
+        lo2 = min(lo2, __shfl_xor(lo2, o)); hi2 = max(hi2, __shfl_xor(hi2, o));
+    }
+    if (lane == 0) {
+        red[w] = lo0; red[WAVES_PER_BLOCK + w] = lo1; red[2 * WAVES_PER_BLOCK + w] = lo2;
+        red[3 * WAVES_PER_BLOCK + w] = hi0; red[4 * WAVES_PER_BLOCK + w] = hi1;
+        red[5 * WAVES_PER_BLOCK + w] = hi2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WAVES_PER_BLOCK; k++) {
+        lo0 = min(lo0, red[k]); lo1 = min(lo1, red[WAVES_PER_BLOCK + k]);
+        lo2 = min(lo2, red[2 * WAVES_PER_BLOCK + k]);
+        hi0 = max(hi0, red[3 * WAVES_PER_BLOCK + k]); hi1 = max(hi1, red[4 * WAVES_PER_BLOCK + k]);
+        hi2 = max(hi2, red[5 * WAVES_PER_BLOCK + k]);
+    }
+    lo0 = uniform(lo0); lo1 = uniform(lo1); lo2 = uniform(lo2);
+    hi0 = uniform(hi0); hi1 = uniform(hi1); hi2 = uniform(hi2);
+    if (hi0 < 0) return;              // no ray of the tile reaches this chunk
+#if defined(RN_BOX_SKIP) && (RN_BOX_SKIP & 4)
+    return;
+#endif
+    const int d0 = hi0 - lo0 + 1, d1 = hi1 - lo1 + 1, d2 = hi2 - lo2 + 1;
+    const int V = d0 * d1 * d2;
+    const bool dense = V <= BOX_CAP;
+    if (dense)
+        for (int i = tid; i < V; i += BLOCK) box[i] = 0.0;
+    __syncthreads();
+#ifdef RN_SCATTER_STATS
+    if (tid == 0) {
+        atomicAdd(&g_scatter_stats[0], 1ull);
+        atomicAdd(&g_scatter_stats[1], dense ? 1ull : 0ull);
+        atomicAdd(&g_scatter_stats[2], (unsigned long long)V);
+    }
+#endif
+    // ---- contributions: a wavefront instruction covers WAVE / BOX_STEPS rays x BOX_STEPS steps;
+    // BOX_NB instructions' loads are in flight before the first LDS add
+    {
+        constexpr int RPI = WAVE / BOX_STEPS;
+        constexpr int STRIDE = WAVES_PER_BLOCK * RPI;
+        constexpr int NB = BOX_NB;
+        const int sub = lane / BOX_STEPS, col = lane % BOX_STEPS;
+        const int st = s0 + col;
+        for (int j0 = w * RPI + sub; j0 < BOX_RAYS; j0 += STRIDE * NB) {
+            float m[NB];
+            int x[NB], y[NB], z[NB];
+            bool ok[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int j = j0 + k * STRIDE;
+                ok[k] = j < BOX_RAYS && st < cnts[min(j, BOX_RAYS - 1)];
+                // rows of padding / short rays are read at the tile's first row: valid memory
+                const int rr = ok[k] ? r0 + j : r0, ss = ok[k] ? st : 0;
+                m[k] = msgs[(size_t)rr * p.M + ss];
+                load_voxel<PACKED>(vox + (size_t)rr * p.M * vstride, ss, x[k], y[k], z[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                if (!ok[k]) continue;
+                const unsigned ux = x[k] - lo0, uy = y[k] - lo1, uz = z[k] - lo2;
+                if (dense && ux < (unsigned)d0 && uy < (unsigned)d1 && uz < (unsigned)d2) {
+#if defined(RN_BOX_SKIP) && (RN_BOX_SKIP & 1)
+                    asm volatile("" ::"v"((ux * d1 + uy) * d2 + uz), "v"(m[k]));
+#else
+                    __hip_atomic_fetch_add(box + (ux * d1 + uy) * d2 + uz, (double)m[k],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+                } else {
+                    __hip_atomic_fetch_add(acc_out + ((x[k] * p.gy + y[k]) * p.gz + z[k]), m[k],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+    if (!dense) return;
+#if defined(RN_BOX_SKIP) && (RN_BOX_SKIP & 2)
+    return;
+#endif
+    __syncthreads();
+    // ---- flush, z fastest; (i0, i1, i2) advance by BLOCK elements without divisions
+    {
+        int i2 = tid % d2, t = tid / d2;
+        int i1 = t % d1, i0 = t / d1;
+        const int sz = BLOCK % d2, ty = BLOCK / d2;
+        const int sy = ty % d1, sx = ty / d1;
+        for (int i = tid; i < V; i += BLOCK) {
+            const float v = (float)box[i];
+            if (v != 0.0f) {
+#ifdef RN_SCATTER_STATS
+                atomicAdd(&g_scatter_stats[3], 1ull);
+#endif
+                __hip_atomic_fetch_add(acc_out + (((lo0 + i0) * p.gy + lo1 + i1) * p.gz + lo2 + i2), v,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            i2 += sz;
+            if (i2 >= d2) { i2 -= d2; i1++; }
+            i1 += sy;
+            if (i1 >= d1) { i1 -= d1; i0++; }
+            i0 += sx;
+        }
+    }
+}
+
 // ------------------------------------------------- K4 / K2 tail: depth estimate
 // Writes the distribution (if S_new) and/or the arg-max depth (if depth_map).
 template <int NCH, bool PACKED, bool CLIP_IN>
@@ -1000,7 +1173,7 @@ struct rn_ctx {
     int copies;           // accumulator copies used by the resident path
     int acc_mode;         // 0: one accumulator copy; 1: one copy per XCD (A/B knob)
     bool fused_scatter;   // scatter from inside k_bp instead of a scatter kernel (A/B knob)
-    int scatter_mode;     // 0: slab-ordered (default), 1: step-ordered tile (A/B knob)
+    int scatter_mode;     // A/B knob: -1 by row layout (default), 0 slab, 1 step-ordered tile, 2 LDS box
     hipEvent_t ev0, ev1;
     // per-launch profiling (rn_prof_begin / rn_prof_end)
     bool prof_on;
@@ -1123,7 +1296,7 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
 template <bool PACKED, bool CLIP_IN>
 int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
               const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
-              int64_t xcd_stride, hipStream_t st) {
+              int64_t xcd_stride, hipStream_t st, bool patch_rows = false) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     const bool fused = ctx->fused_scatter;
     // measurement knob: dynamic LDS reserved per block only to cap the occupancy
@@ -1153,9 +1326,16 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     RN_LAUNCH_CHECK(ctx);
     if (!fused) {
         ProfScope prof(ctx, RN_K_SCATTER, n, st);
-        if (ctx->scatter_mode == 1)
+        const int mode = ctx->scatter_mode >= 0 ? ctx->scatter_mode : (patch_rows ? 2 : 0);
+        if (mode == 1)
             hipLaunchKernelGGL((k_scatter_tile<PACKED>), dim3((n + WAVE - 1) / WAVE), dim3(BLOCK),
                                0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, xcd_stride);
+        else if (mode == 2)
+            hipLaunchKernelGGL((k_scatter_box<PACKED>),
+                               dim3(((n + BOX_RAYS - 1) / BOX_RAYS) *
+                                    ((ctx->p.M + BOX_STEPS - 1) / BOX_STEPS)),
+                               dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
+                               xcd_stride);
         else
             hipLaunchKernelGGL((k_scatter_slab<PACKED>),
                                dim3(((n + WAVE - 1) / WAVE) *
@@ -1231,7 +1411,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     if (ctx->acc_mode < 0 || ctx->acc_mode > 1) ctx->acc_mode = 0;
     ctx->fused_scatter = getenv("RAYNET_HIP_FUSED_SCATTER") != nullptr;
     const char *sm = getenv("RAYNET_HIP_SCATTER_MODE");
-    ctx->scatter_mode = sm ? atoi(sm) : 0;
+    ctx->scatter_mode = sm ? atoi(sm) : -1;
     ctx->copies = ctx->acc_mode == 0 ? 1 : NXCD;
     if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
@@ -1561,14 +1741,15 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
 
 int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                       const int32_t *rvc, const float *acc_in, float *msgs, float *acc_part,
-                      int32_t first_sweep, void *stream) {
+                      int32_t first_sweep, int32_t row_layout, void *stream) {
     if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc_in || !msgs || !acc_part)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
     const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
     return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, first_sweep ? nullptr : msgs,
-                                  acc_part, msgs, ctx->acc_mode == 1 ? G : 0, S(stream));
+                                  acc_part, msgs, ctx->acc_mode == 1 ? G : 0, S(stream),
+                                  row_layout == RN_ROWS_PATCHES);
 }
 
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream) {

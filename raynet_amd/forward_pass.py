@@ -88,6 +88,19 @@ def sweep_order(ray_idxs, H, W, images):
     return None
 
 
+def tile_order(ray_idxs, H, W, tile_x, tile_y):
+    """The ray list (idx = x*H + y, sampling_schemes.cu:5-8) re-ordered into tile_x x tile_y
+    pixel patches: consecutive rows of the per-ray buffers are then neighbouring rays in BOTH
+    image directions, so a scatter tile of 256 rows sums ~13 rays per voxel in LDS before it
+    touches the accumulator (k_scatter_box).  Row order never changes results -- every
+    per-ray quantity is computed from the ray index -- only where a ray's row lives."""
+    idx = ray_idxs.to(torch.int64)
+    x, y = idx // H, idx % H
+    tiles_y = (H + tile_y - 1) // tile_y
+    key = (((x // tile_x) * tiles_y + y // tile_y) * tile_x + x % tile_x) * tile_y + y % tile_y
+    return ray_idxs[torch.argsort(key)].to(torch.int32).contiguous()
+
+
 def shard_bounds(n, rank, world):
     """Contiguous slice [lo, hi) of an n-long ray list owned by `rank`."""
     return (n * rank) // world, (n * (rank + 1)) // world
@@ -242,14 +255,20 @@ class RayNetForwardPass(ForwardPass):
         self._backend_factory = backend_factory
         # schedule knob only; results do not depend on it (RAYNET_SWEEP_REORDER=0 for A/B runs)
         self.sweep_reorder = os.environ.get("RAYNET_SWEEP_REORDER", "1") != "0"
+        # row layout of the resident buffers: 16x16 pixel patches (RAYNET_RAY_TILE=0: ray-index
+        # order, AxB: other patch shapes; A/B knob, results do not depend on it)
+        tile = os.environ.get("RAYNET_RAY_TILE", "16x16")
+        self.ray_tile = tuple(int(t) for t in tile.split("x")) if "x" in tile else None
+        self._ray_lists = {}
         self.ref_idx = -1
         self._ctx = None
         self._de = None
         self.timings = {}
         # state kept for inspection by tests / tools
         self.accumulator = None
-        self.messages = {}
+        self.messages = {}       # per image: [rows, M] messages of this rank's rays
         self.voxel_count = {}
+        self.ray_index = {}      # per image: ray index (pixel x*H + y) of every row
 
     # -- helpers -----------------------------------------------------------
     def _context(self, scene, F):
@@ -343,19 +362,29 @@ class RayNetForwardPass(ForwardPass):
         # per-image launches the tail of each launch (and, on 8 GPUs, its fixed cost) adds up
         V = len(refs)
         shards = []
+        lists = {}
+        patch_rows = self.ray_tile is not None
         for k, r in enumerate(refs):
+            # the image's ray list in ROW order (what row i of its buffers holds)
             if self._filter_out_rays:
-                ray_idxs = self.get_valid_rays_per_image(scene, r)
-                total = len(ray_idxs)
-                lo, hi = shard_bounds(total, rank, world)
-                ridx = ctx.dev(np.ascontiguousarray(ray_idxs[lo:hi].astype(np.int32)))
-            else:       # all H*W rays (forward_pass.py:166-168): built on the device
-                total = H * W
-                lo, hi = shard_bounds(total, rank, world)
-                ridx = torch.arange(lo, hi, dtype=torch.int32, device=dev)
-            shards.append((ridx, lo, hi, total))
+                rays = ctx.dev(np.ascontiguousarray(
+                    self.get_valid_rays_per_image(scene, r).astype(np.int32)))
+                if patch_rows:
+                    rays = tile_order(rays, H, W, *self.ray_tile)
+            else:       # all H*W rays (forward_pass.py:166-168): built on the device, once
+                key = (H, W, self.ray_tile, str(dev))
+                if key not in self._ray_lists:
+                    rays = torch.arange(H * W, dtype=torch.int32, device=dev)
+                    if patch_rows:
+                        rays = tile_order(rays, H, W, *self.ray_tile)
+                    self._ray_lists[key] = rays
+                rays = self._ray_lists[key]
+            total = len(rays)
+            lo, hi = shard_bounds(total, rank, world)
+            lists[r] = rays
+            shards.append((rays[lo:hi], lo, hi, total))
         npad = max([len(sh[0]) for sh in shards] + [1])
-        npad = (npad + 63) // 64 * 64            # scatter tiles never straddle two images
+        npad = (npad + 255) // 256 * 256            # scatter tiles never straddle two images
         vox_all = torch.empty((V * npad, M), dtype=torch.int32, device=dev)
         Sr_all = torch.empty((V * npad, M), dtype=torch.float32, device=dev)
         msgs_all = torch.zeros((V * npad, M), dtype=torch.float32, device=dev)
@@ -366,13 +395,16 @@ class RayNetForwardPass(ForwardPass):
             ridx, lo, hi, total = shards[k]
             n = len(ridx)
             row0 = k * npad
+            self.ray_index[r] = ridx
             per_image[r] = dict(ridx=ridx, n=n, lo=lo, hi=hi, total=total, row0=row0,
                                 center=cam_dev[k, 12 * N + 12:],
                                 vox=vox_all[row0:row0 + n], rvc=rvc_all[row0:row0 + n],
                                 Sr=Sr_all[row0:row0 + n], msgs=msgs_all[row0:row0 + n])
 
         def order_for(ridx_slice, lo_i, hi_i, images):
-            if not self.sweep_reorder or sweep_direction(H, W, images) != "rows":
+            # patch rows are already compact in both image directions (measured: the
+            # row-major schedule gains nothing on top of them)
+            if patch_rows or not self.sweep_reorder or sweep_direction(H, W, images) != "rows":
                 return None
             key = (lo_i, hi_i)
             if self._filter_out_rays or key not in orders:
@@ -407,7 +439,7 @@ class RayNetForwardPass(ForwardPass):
                                       st["Sr"][i:i + B], order=order)
 
         n_all = V * npad
-        B_all = self.rays_batch // 64 * 64 if self.rays_batch and self.rays_batch >= 64 else n_all
+        B_all = self.rays_batch // 256 * 256 if self.rays_batch and self.rays_batch >= 256 else n_all
         for it in range(self.bp_iterations):
             # iteration 0 starts from zero messages (forward_pass.py:613-615); with the
             # shipped quirk every iteration does (memmap reopened with mode="w+", Q1)
@@ -415,7 +447,7 @@ class RayNetForwardPass(ForwardPass):
             for i in range(0, n_all, B_all):
                 ctx.scene_bp_sweep(Sr_all[i:i + B_all], vox_all[i:i + B_all],
                                    rvc_all[i:i + B_all], acc_in, msgs_all[i:i + B_all],
-                                   acc_part, first_sweep=first)
+                                   acc_part, first_sweep=first, patch_rows=patch_rows)
             # swap + prior refill of forward_pass.py:676-678; across ranks the prior is
             # added once, after the sum
             if world > 1:
@@ -463,13 +495,19 @@ class RayNetForwardPass(ForwardPass):
                     depth_all[st["row0"]:st["row0"] + st["n"]]
             dist.all_reduce(merged, op=dist.ReduceOp.SUM)
         pending = []
+        identity = not patch_rows and not self._filter_out_rays
         for k, r in enumerate(refs):
             st = per_image[r]
             if world > 1:
                 src = merged[int(offs[k]):int(offs[k + 1])]
             else:
                 src = depth_all[st["row0"]:st["row0"] + st["n"]]
-            host = torch.empty((st["total"],), dtype=torch.float32, pin_memory=dev.type == "cuda")
+            if not identity:
+                # rows -> pixels on the device (rays that were filtered out stay 0)
+                full = torch.zeros((H * W,), dtype=torch.float32, device=dev)
+                full.index_copy_(0, lists[r].long(), src)
+                src = full
+            host = torch.empty((H * W,), dtype=torch.float32, pin_memory=dev.type == "cuda")
             host.copy_(src, non_blocking=True)
             done = torch.cuda.Event() if dev.type == "cuda" else None
             if done is not None:
@@ -481,13 +519,7 @@ class RayNetForwardPass(ForwardPass):
             if done is not None:
                 done.synchronize()
             self.ref_idx = r
-            d = host.numpy()
-            if self._filter_out_rays:
-                full = np.zeros((H * W,), dtype=np.float32)
-                full[self.get_valid_rays_per_image(scene, r)] = d
-                yield full.reshape(W, H).T
-            else:
-                yield d.reshape(W, H).T
+            yield host.numpy().reshape(W, H).T
 
     def _forward_pass_reference(self, scene, images_range):
         """Literal schedule of forward_pass.py:579-748 with K1 / K2 (single rank)."""

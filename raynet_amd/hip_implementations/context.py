@@ -244,10 +244,12 @@ class HipContext(object):
             _ptr(feature_table), _ptr(cameras), _ptr(order), _ptr(vox), _ptr(rvc), _ptr(Sr),
             _stream()))
 
-    def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False):
+    def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False,
+                       patch_rows=False):
         self._check(self.lib.rn_scene_bp_sweep(self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc),
                                                _ptr(acc_in), _ptr(msgs), _ptr(acc_part),
-                                               1 if first_sweep else 0, _stream()))
+                                               1 if first_sweep else 0, 1 if patch_rows else 0,
+                                               _stream()))
 
     def acc_combine(self, acc_part, prior, acc_out):
         self._check(self.lib.rn_acc_combine(self._h, _ptr(acc_part), float(prior), _ptr(acc_out),

@@ -48,7 +48,8 @@ class OracleBackend(object):
         rvc.numpy()[...] = cnt
         Sr.numpy()[...] = Sv        # clipped + renormalised inside the oracle's BP / depth calls
 
-    def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False):
+    def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False,
+                       patch_rows=False):
         if first_sweep:
             msgs.zero_()
         m = np.ascontiguousarray(msgs.numpy())

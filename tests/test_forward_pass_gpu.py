@@ -91,7 +91,9 @@ def test_resident_vs_reference_schedule_vs_oracle(torch, oracle_mod, quirks):
     for i, r in enumerate([0, 1, 2]):
         assert _depth_close(da[i], depth_o[i], dist_o[i], W, H) <= 0.01
         assert _depth_close(db[i], depth_o[i], dist_o[i], W, H) <= 0.01
-        m = fa.messages[r].cpu().numpy()
+        rows = fa.messages[r].cpu().numpy()        # row i belongs to ray fa.ray_index[r][i]
+        m = np.zeros_like(rows)
+        m[fa.ray_index[r].cpu().numpy().astype(np.int64)] = rows
         # three coupled iterations: every message inherits the (float-atomic ordered)
         # accumulator's rounding, amplified by the logit conditioning exp(|m|)
         tol = 2e-3 + 512 * 2.0 ** -24 * np.exp(np.minimum(np.abs(msgs_o[r]), 17.0))
@@ -289,3 +291,36 @@ def test_sharded_ranks_on_real_kernels(torch, tmp_path):
     assert np.array_equal(r0["acc"], r1["acc"]) and np.array_equal(r0["depth"], r1["depth"])
     assert np.abs(one["acc"] - r0["acc"]).max() < 5e-3
     assert (np.abs(one["depth"] - r0["depth"]) > 1e-4).mean() < 0.01
+
+
+@pytest.mark.parametrize("filter_rays", [False, True])
+def test_row_layout_does_not_change_results(torch, filter_rays, monkeypatch):
+    """16x16-patch rows (default) vs ray-index rows: same depth maps, same accumulator up to
+    the summation order of the scatter; ray_index maps rows back to rays."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W, D, M, grid = 40, 56, 16, 96, (32, 32, 32)
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    if filter_rays:
+        rng = np.random.default_rng(0)
+        masks = {i: (rng.random((H, W)) > 0.3).astype(np.float32) for i in range(5)}
+        monkeypatch.setattr(type(scene), "get_depth_map", lambda self, i: masks[i], raising=False)
+    cls = get_forward_pass_factory("raynet")
+    res = {}
+    for tile in ((16, 16), None, (8, 32)):
+        fp = cls(bank, _gp(D, M, grid), "sample_in_bbox", (H, W), 0, filter_out_rays=filter_rays)
+        fp.ray_tile = tile
+        depths = list(fp.forward_pass(scene, (0, 3, 1)))
+        rows = fp.messages[1].cpu().numpy()
+        m = np.zeros((H * W, M), np.float32)
+        m[fp.ray_index[1].cpu().numpy().astype(np.int64)] = rows
+        res[tile] = (np.stack(depths), fp.accumulator.cpu().numpy(), m)
+    ref = res[None]
+    if filter_rays:
+        assert (ref[0][0][masks[0] == 0] == 0).all() and (ref[0][0][masks[0] != 0] > 0).any()
+    for tile in ((16, 16), (8, 32)):
+        d, acc, m = res[tile]
+        assert np.abs(acc - ref[1]).max() < 2e-3
+        assert (np.abs(d - ref[0]) > 1e-4).mean() < 0.01
+        tol = 2e-3 + 512 * 2.0 ** -24 * np.exp(np.minimum(np.abs(ref[2]), 17.0))
+        assert np.all(np.abs(m - ref[2]) <= tol)

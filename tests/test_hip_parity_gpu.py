@@ -665,3 +665,94 @@ def test_rays_missing_the_box(torch, oracle_mod):
     de(ridx, feats, c["P"], c["P_inv"], c["center"], vg2, rvi, rvc, Sv, prior, msgs, depth)
     expect = np.sqrt(((vg2[0, 0, 0] - c["center"][:3]) ** 2).sum())
     assert np.allclose(depth.cpu().numpy(), expect, rtol=1e-6)
+
+
+@pytest.mark.parametrize("layout", ["linear", "patches", "shuffled"])
+def test_box_scatter_equals_direct_sum(torch, oracle_mod, layout):
+    """rn_scene_bp_sweep(row_layout=RN_ROWS_PATCHES) sums a tile's messages in an LDS image
+    of its bounding box before touching the accumulator; whatever the row order (16x16
+    patches = the fast case, ray-index order, a random shuffle = boxes that overflow LDS and
+    fall back to direct atomics) the accumulator equals the float64 sum of the messages."""
+    from raynet_amd.forward_pass import tile_order
+    H, W, M, D, grid = 64, 48, 96, 16, (48, 48, 48)
+    o = oracle_mod.Oracle(M=M, D=D, N=2, F=4, H=H, W=W, padding=3, bbox=[-1, -1, -1, 1, 1, 1],
+                          grid_shape=grid)
+    from raynet_amd.hip_implementations import get_context
+    ctx = get_context(M, D, 2, 4, H, W, 3, [-1, -1, -1, 1, 1, 1], grid)
+    vg = oracle_mod.voxel_grid_centers(np.array([-1, -1, -1, 1, 1, 1], np.float32), grid)
+    ctx.set_voxel_grid(torch.from_numpy(vg).cuda())
+    # a pinhole in front of the box: neighbouring pixels -> neighbouring rays
+    n = H * W
+    idx = torch.arange(n, dtype=torch.int32)
+    if layout == "patches":
+        idx = tile_order(idx, H, W, 16, 16)
+    elif layout == "shuffled":
+        idx = idx[torch.randperm(n, generator=torch.Generator().manual_seed(0))]
+    x, y = (idx // H).numpy().astype(np.float32), (idx % H).numpy().astype(np.float32)
+    cam = np.array([0.1, -0.2, -3.0], np.float32)
+    tgt = np.stack([(x / W - 0.5) * 1.8, (y / H - 0.5) * 1.8, np.ones(n, np.float32)], 1)
+    d = tgt - cam
+    starts = (cam + d * (2.0 / d[:, 2:3])).astype(np.float32)       # plane z = -1
+    ends = (cam + d * (4.0 / d[:, 2:3])).astype(np.float32)         # plane z = +1
+    rvi, rvc = o.traversal(starts, ends)
+    assert rvc.max() > 40 and rvc.max() <= M
+    rng = np.random.default_rng(1)
+    Sr = rng.random((n, M)).astype(np.float32) + 0.01
+    Sr *= np.arange(M)[None, :] < rvc[:, None]
+    Sr /= np.maximum(Sr.sum(1, keepdims=True), 1e-30)
+    packed = ((rvi[..., 0] << 20) | (rvi[..., 1] << 10) | rvi[..., 2]).astype(np.int32)
+    G = tuple(grid)
+    prior_v = float(np.float32(np.log(0.05) - np.log(0.95)))
+    acc_in = torch.full(G, prior_v, device="cuda")
+    outs = {}
+    for patch_rows in (False, True):
+        part = torch.zeros((ctx.acc_copies(),) + G, device="cuda")
+        msgs = torch.zeros((n, M), device="cuda")
+        ctx.scene_bp_sweep(torch.from_numpy(Sr).cuda(), torch.from_numpy(packed).cuda(),
+                           torch.from_numpy(rvc).cuda(), acc_in, msgs, part, first_sweep=True,
+                           patch_rows=patch_rows)
+        outs[patch_rows] = (part.sum(0).cpu().numpy(), msgs.cpu().numpy())
+    assert np.array_equal(outs[False][1], outs[True][1])           # same k_bp, same messages
+    m = outs[True][1].astype(np.float64)
+    truth = np.zeros(G, np.float64)
+    for r in range(n):
+        c = int(rvc[r])
+        if c > 1:
+            np.add.at(truth, tuple(rvi[r, :c].T), m[r, :c])
+    scale = np.abs(truth).max()
+    assert np.abs(outs[True][0] - truth).max() < 2e-6 * scale
+    assert np.abs(outs[False][0] - truth).max() < 2e-5 * scale
+
+
+def test_box_scatter_with_caller_made_voxel_lists(torch, oracle_mod):
+    """Voxel lists that are NOT a DDA walk (random, repeated voxels): elements outside the
+    tile's end-point box take the direct-atomic route; sums stay exact."""
+    M, D, grid = 32, 8, (16, 16, 16)
+    from raynet_amd.hip_implementations import get_context
+    ctx = get_context(M, D, 2, 4, 8, 8, 3, [-1, -1, -1, 1, 1, 1], grid)
+    vg = oracle_mod.voxel_grid_centers(np.array([-1, -1, -1, 1, 1, 1], np.float32), grid)
+    ctx.set_voxel_grid(torch.from_numpy(vg).cuda())
+    rng = np.random.default_rng(3)
+    n = 700                                   # not a multiple of the tile
+    rvi = rng.integers(0, 16, size=(n, M, 3)).astype(np.int32)
+    rvi[:50] = rvi[0]                          # many rays through identical voxels
+    rvc = rng.integers(0, M + 1, size=n).astype(np.int32)
+    Sr = rng.random((n, M)).astype(np.float32) + 0.01
+    Sr *= np.arange(M)[None, :] < rvc[:, None]
+    Sr /= np.maximum(Sr.sum(1, keepdims=True), 1e-30)
+    packed = ((rvi[..., 0] << 20) | (rvi[..., 1] << 10) | rvi[..., 2]).astype(np.int32)
+    G = tuple(grid)
+    acc_in = torch.full(G, -2.9, device="cuda")
+    part = torch.zeros((ctx.acc_copies(),) + G, device="cuda")
+    msgs = torch.zeros((n, M), device="cuda")
+    ctx.scene_bp_sweep(torch.from_numpy(Sr).cuda(), torch.from_numpy(packed).cuda(),
+                       torch.from_numpy(rvc).cuda(), acc_in, msgs, part, first_sweep=True,
+                       patch_rows=True)
+    m = msgs.cpu().numpy().astype(np.float64)
+    truth = np.zeros(G, np.float64)
+    for r in range(n):
+        c = int(rvc[r])
+        if c > 1:
+            np.add.at(truth, tuple(rvi[r, :c].T), m[r, :c])
+    assert np.isfinite(m).all()
+    assert np.abs(part.sum(0).cpu().numpy() - truth).max() < 1e-5 * max(1.0, np.abs(truth).max())
