@@ -196,8 +196,16 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
                          const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
                          float *Sr, void *stream);
 
-/* acc_part: [rn_acc_copies()][gx][gy][gz] f32, zero before the first sweep of an
+/* Accumulators of the resident path are stored as 4x4x4 bricks,
+ * [ceil(gx/4)][ceil(gy/4)][ceil(gz/4)][4][4][4] f32 = rn_acc_size() floats (a ray stays
+ * inside a brick for ~4 steps, so a wavefront's gather touches ~4x fewer cache lines than in
+ * the [gx][gy][gz] array).  rn_acc_to_grid / rn_acc_from_grid convert to / from the
+ * reference's [gx][gy][gz] layout (mrf_bp.cu:3-10); padding voxels are never read back.
+ * acc_part: [rn_acc_copies()][rn_acc_size()] f32, zero before the first sweep of an
  * iteration; messages are scattered into one copy per XCD. */
+int64_t rn_acc_size(const rn_ctx *ctx);
+int rn_acc_to_grid(rn_ctx *ctx, const float *acc, float *grid_out, void *stream);
+int rn_acc_from_grid(rn_ctx *ctx, const float *grid, float *acc_out, void *stream);
 int rn_acc_copies(const rn_ctx *ctx);
 /* first_sweep != 0: the messages are taken as zero and `msgs` is only written, so it
  * needs no zero-fill (the reference zero-fills for iteration 0, forward_pass.py:613-615).

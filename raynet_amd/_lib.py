@@ -83,6 +83,9 @@ SIGNATURES = {
     "rn_scene_prepare": [_P, _I, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P],
     "rn_scene_prepare_all": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "rn_acc_copies": [_P],
+    "rn_acc_size": [_P],
+    "rn_acc_to_grid": [_P, _P, _P, _P],
+    "rn_acc_from_grid": [_P, _P, _P, _P],
     "rn_scene_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "rn_acc_combine": [_P, _P, _F, _P, _P],
     "rn_acc_reduce_local": [_P, _P, _P, _P],
@@ -119,5 +122,6 @@ def load():
     lib.rn_destroy.restype = None
     lib.rn_last_error.restype = ctypes.c_char_p
     lib.rn_version.restype = ctypes.c_char_p
+    lib.rn_acc_size.restype = ctypes.c_int64
     _lib = lib
     return lib

@@ -67,6 +67,19 @@ __global__ void k_acc_combine(float *part, int copies, int64_t G, float prior, f
         out[i] = add_prior ? prior + s : s;
     }
 }
+// resident (bricked) accumulator <-> the reference's [gx][gy][gz] array
+template <bool TO_GRID>
+__global__ void k_acc_regrid(Params p, const float *__restrict__ src, float *dst) {
+    const int64_t G = (int64_t)p.gx * p.gy * p.gz;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < G;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int z = (int)(i % p.gz), y = (int)((i / p.gz) % p.gy), x = (int)(i / ((int64_t)p.gz * p.gy));
+        const int64_t b = ((((int64_t)(x >> 2) * p.nby + (y >> 2)) * p.nbz + (z >> 2)) << 6) |
+                          ((x & 3) << 4) | ((y & 3) << 2) | (z & 3);
+        if (TO_GRID) dst[i] = src[b];
+        else dst[b] = src[i];
+    }
+}
 __global__ void k_add_scalar(float *a, int64_t n, float v) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
@@ -372,80 +385,80 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
 //            instruction).  The drivers use SCATTER=false + k_scatter_slab instead.
 //   msgs_in == nullptr means "all messages are zero" (first sweep): nothing is read.
 // The kernel is latency bound (about three dependent memory round trips per ray), so the
-// rows of the first SPEC chunks are requested before the ray's voxel count is known: the
-// rows are M long for every ray, entries past the count are loaded and ignored.
-#ifndef RN_SPEC
-#define RN_SPEC 1
-#endif
-constexpr int SPEC = RN_SPEC;   // chunks whose rows are requested before the count is known
 template <bool PACKED>
 __device__ __forceinline__ int load_packed(const int32_t *__restrict__ row, int i) {
     if (PACKED) return row[i];
     return pack_voxel(row[3 * i], row[3 * i + 1], row[3 * i + 2]);
 }
+// Accumulator index of a voxel.  The reference's accumulators are [gx][gy][gz] arrays
+// (mrf_bp.cu:3-10) and the K1-K4 entry points keep that.  The resident-scene path (BRICK)
+// stores them as 4x4x4 bricks, [gx/4][gy/4][gz/4][4][4][4]: a ray steps through ~4 voxels of
+// a brick in a row, so the 64 gathers of a wavefront instruction fall into ~16 cache lines
+// instead of 64 when the ray does not travel along z.  Measured: the gather is the largest
+// single cost of k_bp (no gather: -37 %); bricks take half of it back.
+template <bool BRICK>
+__device__ __forceinline__ int lin_xyz(const Params &p, int x, int y, int z) {
+    if (BRICK)
+        return ((((x >> 2) * p.nby + (y >> 2)) * p.nbz + (z >> 2)) << 6) | ((x & 3) << 4) |
+               ((y & 3) << 2) | (z & 3);
+    return (x * p.gy + y) * p.gz + z;
+}
+template <bool BRICK>
 __device__ __forceinline__ int lin_of(const Params &p, int v) {
-    return ((v >> 20) * p.gy + ((v >> 10) & 1023)) * p.gz + (v & 1023);
+    return lin_xyz<BRICK>(p, v >> 20, (v >> 10) & 1023, v & 1023);
+}
+__device__ __forceinline__ float gather_acc(const float *__restrict__ acc, int lin) {
+    return acc[lin];
 }
 
-template <int NCH, bool PACKED, bool CLIP_IN, bool SCATTER>
-__global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
-                                              const int32_t *__restrict__ vox,
-                                              const int32_t *__restrict__ rvc,
-                                              const float *__restrict__ acc_in,
-                                              const float *msgs_in, float *acc_out,
-                                              float *msgs_out, int64_t xcd_stride) {
-    int lane;
-    const int r = ray_of_wave(n, lane);
-    if (r < 0) return;
-    const float *Srow = S + (size_t)r * p.M;
-    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
-    const float *min_row = msgs_in ? msgs_in + (size_t)r * p.M : nullptr;
-    float *mout_row = msgs_out + (size_t)r * p.M;
+// A wavefront walks through RPW consecutive rays.  The counts of all of them are fetched
+// first; while ray j is being computed the rows of ray j+1 are already in flight, so a ray
+// costs one dependent memory round trip (its accumulator gather) instead of three (count ->
+// rows -> gather): measured, the kernel is bound by that chain at 8 waves / SIMD, not by
+// instruction issue.
+#ifndef RN_RPW
+#define RN_RPW 1
+#endif
+constexpr int RPW = RN_RPW;
+inline int ray_group_blocks(int n) {
+    return (n + WAVES_PER_BLOCK * RPW - 1) / (WAVES_PER_BLOCK * RPW);
+}
+// first ray of this wavefront's group (uniform), or -1
+__device__ __forceinline__ int ray_group_of_wave(int n, int &lane) {
+    lane = threadIdx.x & (WAVE - 1);
+    const int b = xcd_block(blockIdx.x, gridDim.x);
+    const int r = (b * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * RPW;
+    return r < n ? uniform(r) : -1;
+}
 
+template <int NCH>
+struct RayRows {
     float sv[NCH], mv[NCH];
     int pk[NCH];
-    // speculative rows
-#pragma unroll
-    for (int ch = 0; ch < NCH && ch < SPEC; ch++) {
-        const int i = ch * WAVE + lane;
-        sv[ch] = 0.0f; mv[ch] = 0.0f; pk[ch] = 0;
-        if (i < p.M) {
-            sv[ch] = Srow[i];
-            pk[ch] = load_packed<PACKED>(vrow, i);
-            if (min_row) mv[ch] = min_row[i];
-        }
-    }
-    const int count = min(uniform(rvc[r]), p.M);
-    if (count <= 1) return;   // mrf_np.py:300
-    if (xcd_stride) {
-        // the XCD this workgroup really runs on; copies are private per XCD
-        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
-        acc_out += xcc * xcd_stride;
-    }
-#pragma unroll
-    for (int ch = SPEC; ch < NCH; ch++) {
-        const int i = ch * WAVE + lane;
-        sv[ch] = 0.0f; mv[ch] = 0.0f; pk[ch] = 0;
-        if (ch * WAVE < count && i < count) {
-            sv[ch] = Srow[i];
-            pk[ch] = load_packed<PACKED>(vrow, i);
-            if (min_row) mv[ch] = min_row[i];
-        }
-    }
-    // accumulator gather (depends on the voxel rows)
-    float av[NCH];
-    int lin[NCH];
+};
+// the first `count` entries of the ray's column, voxel list and (optionally) messages
+template <int NCH, bool PACKED>
+__device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
+                                          const float *__restrict__ S,
+                                          const int32_t *__restrict__ vox, const float *msgs, int r,
+                                          int count, int lane) {
+    const float *Srow = S + (size_t)r * p.M;
+    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+    const float *mrow = msgs ? msgs + (size_t)r * p.M : nullptr;
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         const int i = ch * WAVE + lane;
-        av[ch] = 0.0f;
-        lin[ch] = 0;
+        R.sv[ch] = 0.0f; R.mv[ch] = 0.0f; R.pk[ch] = 0;
         if (ch * WAVE < count && i < count) {
-            lin[ch] = lin_of(p, pk[ch]);
-            av[ch] = acc_in[lin[ch]];
+            R.sv[ch] = Srow[i];
+            R.pk[ch] = load_packed<PACKED>(vrow, i);
+            if (mrow) R.mv[ch] = mrow[i];
         }
     }
-
+}
+// clip to [1e-5, 1-1e-5] and renormalise over the count (mrf_bp.cu:103-111)
+template <int NCH, bool CLIP_IN>
+__device__ __forceinline__ void clip_renorm_rows(float (&sv)[NCH], int count, int lane) {
     float ssum = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
@@ -463,65 +476,117 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) sv[ch] = sv[ch] / ssum;
     }
+}
 
-    // pass A: occupancy, exclusive cumprod T, w = o*T*s, exclusive cumsum C
-    float ov[NCH], tsv[NCH], cex[NCH], wv[NCH];
-    float carryT = 1.0f, carryC = 0.0f;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) {
-        ov[ch] = 0.0f; tsv[ch] = 0.0f; cex[ch] = 0.0f; wv[ch] = 0.0f;
-        if (ch * WAVE < count) {
-            const int i = ch * WAVE + lane;
-            const bool valid = i < count;
-            const float o = valid ? occupancy_to_ray(av[ch], mv[ch]) : 0.0f;
-            const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
-            const float T = carryT * wave_shift1(incl, 1.0f);
-            carryT = carryT * lane63(incl);
-            const float ts = T * sv[ch];
-            const float w = valid ? o * ts : 0.0f;
-            const float inclC = wave_scan_add(w);
-            cex[ch] = carryC + wave_shift1(inclC, 0.0f);
-            carryC = carryC + lane63(inclC);
-            ov[ch] = o;
-            tsv[ch] = ts;
-            wv[ch] = w;
-        }
+template <int NCH, bool PACKED, bool CLIP_IN, bool SCATTER>
+__global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
+                                              const int32_t *__restrict__ vox,
+                                              const int32_t *__restrict__ rvc,
+                                              const float *__restrict__ acc_in,
+                                              const float *msgs_in, float *acc_out,
+                                              float *msgs_out, int64_t xcd_stride) {
+    int lane;
+    const int rbase = ray_group_of_wave(n, lane);
+    if (rbase < 0) return;
+    // counts run two rays ahead (scalar loads), rows one ray ahead
+    auto count_of = [&](int r) {
+        const int c = r < n ? min(uniform(rvc[min(r, n - 1)]), p.M) : 0;
+        return c <= 1 ? 0 : c;         // mrf_np.py:300: such rays send nothing
+    };
+    int count = count_of(rbase), count_nxt = count_of(rbase + 1);
+    if (SCATTER && xcd_stride) {
+        // the XCD this workgroup really runs on; copies are private per XCD
+        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
+        acc_out += xcc * xcd_stride;
     }
-    // (cumsum1 - cumsum2) of mrf_bp.cu:157 is the suffix sum  sum_{j>i} w_j.  The reference
-    // forms it as a difference of two running sums, which is exact-or-zero only because
-    // both are the SAME sequential sum; with wave scans that difference could go negative
-    // by an ulp (log of a negative number -> NaN), so the suffix is scanned directly.  It
-    // is non-negative by construction and free of the reference's cancellation.
-    float suf[NCH];
-    {
-        float carryS = 0.0f;
+    RayRows<NCH> cur, nxt;
+    load_rows<NCH, PACKED>(p, cur, S, vox, msgs_in, rbase, count, lane);
+#pragma unroll 1
+    for (int j = 0; j < RPW; j++) {
+        const int r = rbase + j;
+        const int count_nn = j + 2 < RPW ? count_of(r + 2) : 0;
+        // accumulator gather of this ray (depends on its voxel rows) ...
+        float av[NCH];
+        int lin[NCH];
 #pragma unroll
-        for (int ch = NCH - 1; ch >= 0; ch--) {
-            suf[ch] = 0.0f;
-            if (ch * WAVE < count) {
-                float tot;
-                suf[ch] = carryS + wave_suffix_excl(wv[ch], lane, tot);
-                carryS = carryS + tot;
+        for (int ch = 0; ch < NCH; ch++) {
+            const int i = ch * WAVE + lane;
+            av[ch] = 0.0f;
+            lin[ch] = 0;
+            if (ch * WAVE < count && i < count) {
+                lin[ch] = lin_of<PACKED>(p, cur.pk[ch]);
+                av[ch] = gather_acc(acc_in, lin[ch]);
             }
         }
-    }
+        // ... and, behind it, the rows of the next ray
+        if (j + 1 < RPW) load_rows<NCH, PACKED>(p, nxt, S, vox, msgs_in, r + 1, count_nxt, lane);
+        if (count > 0) {
+            float *mout_row = msgs_out + (size_t)r * p.M;
+            clip_renorm_rows<NCH, CLIP_IN>(cur.sv, count, lane);
 
-    // pass B: messages (mrf_bp.cu:136-167) and, optionally, the scatter (:170-176)
+            // pass A: occupancy, exclusive cumprod T, w = o*T*s, exclusive cumsum C
+            float ov[NCH], tsv[NCH], cex[NCH], wv[NCH];
+            float carryT = 1.0f, carryC = 0.0f;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ch++) {
-        if (ch * WAVE < count) {
-            const int i = ch * WAVE + lane;
-            if (i < count) {
-                float pos = cex[ch] + tsv[ch];
-                const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
-                pos = bp_div(pos, pos + neg);
-                const float m = bp_log(pos) - bp_log(1.0f - pos);
-                mout_row[i] = m;
-                if (SCATTER)
-                    __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+            for (int ch = 0; ch < NCH; ch++) {
+                ov[ch] = 0.0f; tsv[ch] = 0.0f; cex[ch] = 0.0f; wv[ch] = 0.0f;
+                if (ch * WAVE < count) {
+                    const int i = ch * WAVE + lane;
+                    const bool valid = i < count;
+                    const float o = valid ? occupancy_to_ray(av[ch], cur.mv[ch]) : 0.0f;
+                    const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
+                    const float T = carryT * wave_shift1(incl, 1.0f);
+                    carryT = carryT * lane63(incl);
+                    const float ts = T * cur.sv[ch];
+                    const float w = valid ? o * ts : 0.0f;
+                    const float inclC = wave_scan_add(w);
+                    cex[ch] = carryC + wave_shift1(inclC, 0.0f);
+                    carryC = carryC + lane63(inclC);
+                    ov[ch] = o;
+                    tsv[ch] = ts;
+                    wv[ch] = w;
+                }
+            }
+            // (cumsum1 - cumsum2) of mrf_bp.cu:157 is the suffix sum  sum_{j>i} w_j.  The
+            // reference forms it as a difference of two running sums, which is exact-or-zero
+            // only because both are the SAME sequential sum; with wave scans that difference
+            // could go negative by an ulp (log of a negative number -> NaN), so the suffix is
+            // scanned directly.  It is non-negative by construction and free of the
+            // reference's cancellation.
+            float suf[NCH];
+            {
+                float carryS = 0.0f;
+#pragma unroll
+                for (int ch = NCH - 1; ch >= 0; ch--) {
+                    suf[ch] = 0.0f;
+                    if (ch * WAVE < count) {
+                        float tot;
+                        suf[ch] = carryS + wave_suffix_excl(wv[ch], lane, tot);
+                        carryS = carryS + tot;
+                    }
+                }
+            }
+            // pass B: messages (mrf_bp.cu:136-167) and, optionally, the scatter (:170-176)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                if (ch * WAVE < count) {
+                    const int i = ch * WAVE + lane;
+                    if (i < count) {
+                        float pos = cex[ch] + tsv[ch];
+                        const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
+                        pos = bp_div(pos, pos + neg);
+                        const float m = bp_log(pos) - bp_log(1.0f - pos);
+                        mout_row[i] = m;
+                        if (SCATTER)
+                            __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
         }
+        cur = nxt;
+        count = count_nxt;
+        count_nxt = count_nn;
     }
 }
 
@@ -589,7 +654,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_tile(Params p, int n,
             if (base + s < cnt) {
                 const float m = tile_m[lane * TILE_PAD + s];
                 const int32_t v = tile_v[lane * TILE_PAD + s];
-                const int lin = ((v >> 20) * p.gy + ((v >> 10) & 1023)) * p.gz + (v & 1023);
+                const int lin = lin_of<PACKED>(p, v);
                 __hip_atomic_fetch_add(acc_out + lin, m, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -759,7 +824,7 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
                 int lin = -2 - lane;                 // unique: a non-emitting lane is its own run
                 if (emit) {
                     val = tile_m[lane * SLAB_PAD + cursor];
-                    lin = ((vcur >> 20) * p.gy + ((vcur >> 10) & 1023)) * p.gz + (vcur & 1023);
+                    lin = lin_of<PACKED>(p, vcur);
                 }
                 int head = dpp_i<0x111, 0xf>(0x7fffffff, lin) != lin;     // row start: head
 #define RN_SEG_STEP(CTRL)                                             \
@@ -950,7 +1015,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
                 } else {
-                    __hip_atomic_fetch_add(acc_out + ((x[k] * p.gy + y[k]) * p.gz + z[k]), m[k],
+                    __hip_atomic_fetch_add(acc_out + lin_xyz<PACKED>(p, x[k], y[k], z[k]), m[k],
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -973,7 +1038,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
 #ifdef RN_SCATTER_STATS
                 atomicAdd(&g_scatter_stats[3], 1ull);
 #endif
-                __hip_atomic_fetch_add(acc_out + (((lo0 + i0) * p.gy + lo1 + i1) * p.gz + lo2 + i2), v,
+                __hip_atomic_fetch_add(acc_out + lin_xyz<PACKED>(p, lo0 + i0, lo1 + i1, lo2 + i2), v,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             i2 += sz;
@@ -994,124 +1059,100 @@ __global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S
                                                  const float *__restrict__ acc,
                                                  const float *__restrict__ msgs,
                                                  const float *__restrict__ axes,
-                                                 const float *__restrict__ cc, float *S_new,
+                                                 const float *__restrict__ cc_all, float *S_new,
                                                  float *depth_map, int rays_per_center) {
     int lane;
-    const int r = ray_of_wave(n, lane);
-    if (r < 0) return;
-    if (rays_per_center > 0 && cc) cc += 4 * (r / rays_per_center);
-    const float *Srow = S + (size_t)r * p.M;
-    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
-    const float *mrow = msgs + (size_t)r * p.M;
-
-    // rows of the first SPEC chunks are requested before the count is known (see k_bp)
-    float sv[NCH], mv[NCH];
-    int pk[NCH];
-#pragma unroll
-    for (int ch = 0; ch < NCH && ch < SPEC; ch++) {
-        const int i = ch * WAVE + lane;
-        sv[ch] = 0.0f; mv[ch] = 0.0f; pk[ch] = 0;
-        if (i < p.M) {
-            sv[ch] = Srow[i];
-            pk[ch] = load_packed<PACKED>(vrow, i);
-            mv[ch] = mrow[i];
-        }
-    }
-    const int count = min(uniform(rvc[r]), p.M);
-
-    float best = -INFINITY;
-    int best_i = 0;
-    if (count > 1) {
-#pragma unroll
-        for (int ch = SPEC; ch < NCH; ch++) {
-            const int i = ch * WAVE + lane;
-            sv[ch] = 0.0f; mv[ch] = 0.0f; pk[ch] = 0;
-            if (ch * WAVE < count && i < count) {
-                sv[ch] = Srow[i];
-                pk[ch] = load_packed<PACKED>(vrow, i);
-                mv[ch] = mrow[i];
-            }
-        }
+    const int rbase = ray_group_of_wave(n, lane);
+    if (rbase < 0) return;
+    auto count_of = [&](int r) { return r < n ? min(uniform(rvc[min(r, n - 1)]), p.M) : 0; };
+    int count = count_of(rbase), count_nxt = count_of(rbase + 1);
+    // same pipeline as k_bp: rows of ray j+1 in flight while ray j is computed
+    RayRows<NCH> cur, nxt;
+    load_rows<NCH, PACKED>(p, cur, S, vox, msgs, rbase, count > 1 ? count : 0, lane);
+#pragma unroll 1
+    for (int j = 0; j < RPW; j++) {
+        const int r = rbase + j;
+        const int count_nn = j + 2 < RPW ? count_of(r + 2) : 0;
         float av[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {
             const int i = ch * WAVE + lane;
             av[ch] = 0.0f;
-            if (ch * WAVE < count && i < count) av[ch] = acc[lin_of(p, pk[ch])];
+            if (count > 1 && ch * WAVE < count && i < count)
+                av[ch] = gather_acc(acc, lin_of<PACKED>(p, cur.pk[ch]));
         }
-        float wv[NCH];
-        float ssum = 0.0f;
+        if (j + 1 < RPW)
+            load_rows<NCH, PACKED>(p, nxt, S, vox, msgs, r + 1, count_nxt > 1 ? count_nxt : 0, lane);
+        if (r < n) {
+            float best = -INFINITY;
+            int best_i = 0;
+            if (count > 1) {
+                clip_renorm_rows<NCH, CLIP_IN>(cur.sv, count, lane);
+                float wv[NCH];
+                float carryT = 1.0f, wsum = 0.0f;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            const int i = ch * WAVE + lane;
-            float v = 0.0f;
-            if (i < count) {
-                v = sv[ch];
-                if (CLIP_IN) v = clampf(v, (float)1e-5, (float)(1 - 1e-5));
+                for (int ch = 0; ch < NCH; ch++) {
+                    wv[ch] = 0.0f;
+                    if (ch * WAVE < count) {
+                        const int i = ch * WAVE + lane;
+                        const bool valid = i < count;
+                        const float o = valid ? occupancy_to_ray(av[ch], cur.mv[ch]) : 0.0f;
+                        const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
+                        const float T = carryT * wave_shift1(incl, 1.0f);
+                        carryT = carryT * lane63(incl);
+                        wv[ch] = valid ? o * T * cur.sv[ch] : 0.0f;
+                        wsum += wv[ch];
+                    }
+                }
+                wsum = wave_sum(wsum);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) {
+                    const int i = ch * WAVE + lane;
+                    if (ch * WAVE < count && i < count) {
+                        const float d = bp_div(wv[ch], wsum);
+                        if (S_new) S_new[(size_t)r * p.M + i] = d;
+                        if (d > best) {   // ascending i per lane: keeps the first maximum
+                            best = d;
+                            best_i = i;
+                        }
+                    }
+                }
+            } else if (S_new) {
+                // mrf_np.py:370-377: skipped rays keep an all-zero row (first `count` entries)
+                for (int i = lane; i < count; i += WAVE) S_new[(size_t)r * p.M + i] = 0.0f;
             }
-            sv[ch] = v;
-            ssum += v;
-        }
-        if (CLIP_IN) {
-            ssum = wave_sum(ssum);
+            if (depth_map) {
+                // raynet_fp.py:193-226.  Entries beyond count are zero in the reference's
+                // zero-filled buffer and every d_i > 0, so the arg-max lies in [0, count);
+                // for count <= 1 the row is all zeros and index 0 wins.
 #pragma unroll
-            for (int ch = 0; ch < NCH; ch++) sv[ch] = sv[ch] / ssum;
-        }
-        float carryT = 1.0f, wsum = 0.0f;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            wv[ch] = 0.0f;
-            if (ch * WAVE < count) {
-                const int i = ch * WAVE + lane;
-                const bool valid = i < count;
-                const float o = valid ? occupancy_to_ray(av[ch], mv[ch]) : 0.0f;
-                const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
-                const float T = carryT * wave_shift1(incl, 1.0f);
-                carryT = carryT * lane63(incl);
-                wv[ch] = valid ? o * T * sv[ch] : 0.0f;
-                wsum += wv[ch];
-            }
-        }
-        wsum = wave_sum(wsum);
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            const int i = ch * WAVE + lane;
-            if (ch * WAVE < count && i < count) {
-                const float d = bp_div(wv[ch], wsum);
-                if (S_new) S_new[(size_t)r * p.M + i] = d;
-                if (d > best) {   // ascending i per lane: keeps the first maximum
-                    best = d;
-                    best_i = i;
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ob = __shfl_xor(best, o);
+                    const int oi = __shfl_xor(best_i, o);
+                    if (ob > best || (ob == best && oi < best_i)) {
+                        best = ob;
+                        best_i = oi;
+                    }
+                }
+                if (lane == 0) {
+                    const float *cc =
+                        rays_per_center > 0 && cc_all ? cc_all + 4 * (r / rays_per_center) : cc_all;
+                    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+                    int x = 0, y = 0, z = 0;
+                    if (count > 0) load_voxel<PACKED>(vrow, count > 1 ? best_i : 0, x, y, z);
+                    const float pt[3] = {axes[x], axes[p.gx + y], axes[p.gx + p.gy + z]};
+                    float sum = 0.0f;
+                    for (int i = 0; i < 3; i++) {
+                        const float d = pt[i] - cc[i];
+                        sum += d * d;
+                    }
+                    depth_map[r] = sqrtf(sum);
                 }
             }
         }
-    } else if (S_new) {
-        // mrf_np.py:370-377: skipped rays keep an all-zero row (first `count` entries)
-        for (int i = lane; i < count; i += WAVE) S_new[(size_t)r * p.M + i] = 0.0f;
-    }
-    if (!depth_map) return;
-    // raynet_fp.py:193-226.  Entries beyond count are zero in the reference's
-    // zero-filled buffer and every d_i > 0, so the arg-max lies in [0, count);
-    // for count <= 1 the row is all zeros and index 0 wins.
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o);
-        const int oi = __shfl_xor(best_i, o);
-        if (ob > best || (ob == best && oi < best_i)) {
-            best = ob;
-            best_i = oi;
-        }
-    }
-    if (lane == 0) {
-        int x = 0, y = 0, z = 0;
-        if (count > 0) load_voxel<PACKED>(vrow, count > 1 ? best_i : 0, x, y, z);
-        const float pt[3] = {axes[x], axes[p.gx + y], axes[p.gx + p.gy + z]};
-        float sum = 0.0f;
-        for (int i = 0; i < 3; i++) {
-            const float d = pt[i] - cc[i];
-            sum += d * d;
-        }
-        depth_map[r] = sqrtf(sum);
+        cur = nxt;
+        count = count_nxt;
+        count_nxt = count_nn;
     }
 }
 
@@ -1307,12 +1348,12 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
 #define RN_BP(NCH_)                                                                         \
     do {                                                                                    \
         if (fused)                                                                          \
-            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, true>), dim3(ray_blocks(n)), \
+            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, true>), dim3(ray_group_blocks(n)), \
                                dim3(BLOCK), bp_lds, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in,  \
                                acc_out, msgs_out, xcd_stride);                               \
         else                                                                                \
             hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, false>),                   \
-                               dim3(ray_blocks(n)), dim3(BLOCK), bp_lds, st, ctx->p, n, Sv,   \
+                               dim3(ray_group_blocks(n)), dim3(BLOCK), bp_lds, st, ctx->p, n, Sv,   \
                                vox, rvc, acc_in, msgs_in, acc_out, msgs_out, xcd_stride);    \
     } while (0)
         if (nch <= 2) RN_BP(2);
@@ -1354,7 +1395,7 @@ int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const 
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     ProfScope prof(ctx, RN_K_DEPTH, n, st);
 #define RN_DE(NCH_)                                                                             \
-    hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
+    hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_group_blocks(n)), dim3(BLOCK), 0, st, \
                        ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, S_new, depth_map,           \
                        rays_per_center)
     if (nch <= 2) RN_DE(2);
@@ -1366,6 +1407,11 @@ int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const 
 #undef RN_DE
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
+}
+
+// floats of one resident (bricked) accumulator: every axis padded to a multiple of 4
+inline int64_t acc_floats(const rn_ctx *ctx) {
+    return (int64_t)((ctx->p.gx + 3) / 4) * ctx->p.nby * ctx->p.nbz * 64;
 }
 
 int need_axes(rn_ctx *ctx) {
@@ -1394,6 +1440,9 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     for (int i = 0; i < 3; i++)
         if (cfg->grid[i] < 1 || cfg->grid[i] > 1024 || !(cfg->bbox[3 + i] > cfg->bbox[i]))
             return RN_ERR_INVALID;
+    if ((int64_t)((cfg->grid[0] + 3) / 4) * ((cfg->grid[1] + 3) / 4) * ((cfg->grid[2] + 3) / 4) >=
+        ((int64_t)1 << 24))
+        return RN_ERR_INVALID;        // accumulator indices are 32-bit
     if (hipSetDevice(cfg->device) != hipSuccess) return RN_ERR_HIP;
     rn_ctx *ctx = new rn_ctx();
     memset(ctx, 0, sizeof(*ctx));
@@ -1402,6 +1451,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     p.M = cfg->M; p.D = cfg->D; p.N = cfg->N; p.F = cfg->F;
     p.H = cfg->H; p.W = cfg->W; p.padding = cfg->padding;
     p.gx = cfg->grid[0]; p.gy = cfg->grid[1]; p.gz = cfg->grid[2];
+    p.nby = (p.gy + 3) / 4; p.nbz = (p.gz + 3) / 4;
     p.Hf = cfg->H + cfg->padding + 1;
     p.Wf = cfg->W + cfg->padding + 1;
     for (int i = 0; i < 6; i++) p.bbox[i] = cfg->bbox[i];
@@ -1677,6 +1727,26 @@ int rn_fused_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float 
 // ------------------------------------------------------ resident-scene path
 int rn_acc_copies(const rn_ctx *ctx) { return ctx ? ctx->copies : 0; }
 
+int64_t rn_acc_size(const rn_ctx *ctx) { return ctx ? acc_floats(ctx) : 0; }
+
+int rn_acc_to_grid(rn_ctx *ctx, const float *acc, float *grid_out, void *stream) {
+    if (!ctx || !acc || !grid_out) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    hipLaunchKernelGGL((k_acc_regrid<true>), dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream),
+                       ctx->p, acc, grid_out);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_acc_from_grid(rn_ctx *ctx, const float *grid, float *acc_out, void *stream) {
+    if (!ctx || !grid || !acc_out) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    hipLaunchKernelGGL((k_acc_regrid<false>), dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream),
+                       ctx->p, grid, acc_out);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
 int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
                      const float *const *features_views_host, const float *P, const float *P_inv,
                      const float *camera_center, const int32_t *order, int32_t *vox, int32_t *rvc,
@@ -1746,7 +1816,7 @@ int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vo
     if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc_in || !msgs || !acc_part)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
-    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    const int64_t G = acc_floats(ctx);
     return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, first_sweep ? nullptr : msgs,
                                   acc_part, msgs, ctx->acc_mode == 1 ? G : 0, S(stream),
                                   row_layout == RN_ROWS_PATCHES);
@@ -1754,7 +1824,7 @@ int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vo
 
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream) {
     if (!ctx || !acc_part || !acc_out) return fail(ctx, RN_ERR_INVALID, "bad argument");
-    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    const int64_t G = acc_floats(ctx);
     ProfScope prof(ctx, RN_K_ACC, 0, S(stream));
     hipLaunchKernelGGL(k_acc_combine, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream), acc_part,
                        ctx->copies, G, prior, acc_out, 1);
@@ -1764,7 +1834,7 @@ int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, vo
 
 int rn_acc_reduce_local(rn_ctx *ctx, float *acc_part, float *acc_out, void *stream) {
     if (!ctx || !acc_part || !acc_out) return fail(ctx, RN_ERR_INVALID, "bad argument");
-    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    const int64_t G = acc_floats(ctx);
     ProfScope prof(ctx, RN_K_ACC, 0, S(stream));
     hipLaunchKernelGGL(k_acc_combine, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream), acc_part,
                        ctx->copies, G, 0.0f, acc_out, 0);
@@ -1774,7 +1844,7 @@ int rn_acc_reduce_local(rn_ctx *ctx, float *acc_part, float *acc_out, void *stre
 
 int rn_acc_add_prior(rn_ctx *ctx, float *acc, float prior, void *stream) {
     if (!ctx || !acc) return fail(ctx, RN_ERR_INVALID, "bad argument");
-    const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
+    const int64_t G = acc_floats(ctx);
     hipLaunchKernelGGL(k_add_scalar, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream), acc, G,
                        prior);
     RN_LAUNCH_CHECK(ctx);

@@ -24,6 +24,7 @@ constexpr int MAX_VIEWS = 16;
 struct Params {
     int M, D, N, F, H, W, padding;
     int gx, gy, gz;
+    int nby, nbz;        // 4x4x4 bricks along y and z (resident accumulator layout)
     int Hf, Wf;          // feature map extent: H+padding+1, W+padding+1
     float bbox[6];
 };
@@ -44,32 +45,32 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
 }
-// row_shr:1,2,4,8 then row_bcast:15 / row_bcast:31 -- the gfx9 wave64 scan
+// row_shr:1,2,4,8 then row_bcast:15 / row_bcast:31 -- the gfx9 wave64 scan.
+// Written as `v_op_dpp x, x, x` WITHOUT bound_ctrl: a lane whose DPP source is out of range
+// (or whose row is masked) is simply not written, i.e. keeps x -- the identity of any scan
+// operator for free.  Through __builtin_amdgcn_update_dpp the compiler needs three
+// instructions per step for mul / max and for the two row_bcast steps of add (materialise
+// the identity, v_mov_dpp, op).  `s_nop 1`
+// covers the VALU-write -> DPP-read hazard, which the assembler does not insert inside asm.
+#define RN_SCAN_STEP(OP, X, CTRL) \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 " CTRL : "+v"(X))
+#define RN_WAVE_SCAN(OP, X)                                             \
+    RN_SCAN_STEP(OP, X, "row_shr:1 row_mask:0xf bank_mask:0xf");        \
+    RN_SCAN_STEP(OP, X, "row_shr:2 row_mask:0xf bank_mask:0xf");        \
+    RN_SCAN_STEP(OP, X, "row_shr:4 row_mask:0xf bank_mask:0xf");        \
+    RN_SCAN_STEP(OP, X, "row_shr:8 row_mask:0xf bank_mask:0xf");        \
+    RN_SCAN_STEP(OP, X, "row_bcast:15 row_mask:0xa bank_mask:0xf");     \
+    RN_SCAN_STEP(OP, X, "row_bcast:31 row_mask:0xc bank_mask:0xf")
 __device__ __forceinline__ float wave_scan_add(float x) {
-    x += dpp_f<0x111, 0xf>(0.0f, x);
-    x += dpp_f<0x112, 0xf>(0.0f, x);
-    x += dpp_f<0x114, 0xf>(0.0f, x);
-    x += dpp_f<0x118, 0xf>(0.0f, x);
-    x += dpp_f<0x142, 0xa>(0.0f, x);
-    x += dpp_f<0x143, 0xc>(0.0f, x);
+    RN_WAVE_SCAN("v_add_f32_dpp", x);
     return x;
 }
 __device__ __forceinline__ float wave_scan_mul(float x) {
-    x *= dpp_f<0x111, 0xf>(1.0f, x);
-    x *= dpp_f<0x112, 0xf>(1.0f, x);
-    x *= dpp_f<0x114, 0xf>(1.0f, x);
-    x *= dpp_f<0x118, 0xf>(1.0f, x);
-    x *= dpp_f<0x142, 0xa>(1.0f, x);
-    x *= dpp_f<0x143, 0xc>(1.0f, x);
+    RN_WAVE_SCAN("v_mul_f32_dpp", x);
     return x;
 }
 __device__ __forceinline__ int wave_scan_max(int x) {
-    x = max(x, dpp_i<0x111, 0xf>(INT32_MIN, x));
-    x = max(x, dpp_i<0x112, 0xf>(INT32_MIN, x));
-    x = max(x, dpp_i<0x114, 0xf>(INT32_MIN, x));
-    x = max(x, dpp_i<0x118, 0xf>(INT32_MIN, x));
-    x = max(x, dpp_i<0x142, 0xa>(INT32_MIN, x));
-    x = max(x, dpp_i<0x143, 0xc>(INT32_MIN, x));
+    RN_WAVE_SCAN("v_max_i32_dpp", x);
     return x;
 }
 // value of the previous lane (wave_shr:1); lane 0 receives `first`
@@ -388,12 +389,25 @@ __device__ __forceinline__ float bp_log(float x) {
 __device__ __forceinline__ float bp_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float bp_log(float x) { return logf(x); }
 #endif
+// expf(x) for x <= 0: the library's own sequence (extended-precision x*log2(e), v_exp_f32,
+// ldexp, underflow select) minus its overflow select and range constants -- x <= 0 cannot
+// overflow.  Bit-identical to expf for every x <= 0, including -inf (0) and NaN.
+__device__ __forceinline__ float exp_nonpos(float x) {
+    const float log2e_hi = 0x1.715476p+0f, log2e_lo = 0x1.4ae0bep-26f;   // 0x3fb8aa3b, 0x32a5705f
+    const float ph = x * log2e_hi;
+    float pl = __builtin_fmaf(x, log2e_hi, -ph);
+    pl = __builtin_fmaf(x, log2e_lo, pl);
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+    const float r = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+    return x < -0x1.9d1da00000000p+6f ? 0.0f : r;       // 0xc2ce8ed0, the library's underflow bound
+}
 __device__ __forceinline__ float occupancy_to_ray(float acc, float msg) {
     // mrf_bp.cu:12-35
     // t1 = exp(0 - max(0,mu)), t2 = exp(mu - max(0,mu)): one of the two is exp(0) = 1
     // exactly, the other exp(-|mu|) -- one exponential gives both, bit for bit
     const float mu = acc - msg;
-    const float e = expf(0 - fabsf(mu));
+    const float e = exp_nonpos(0 - fabsf(mu));
     const float t1 = mu > 0.0f ? e : 1.0f;
     const float t2 = mu > 0.0f ? 1.0f : e;
     return clampf(bp_div(t2, t1 + t2), 1e-4f, (float)(1 - 1e-4));

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(WAVE) void k_ray_bwd(Params p, int n, const float *
 
     // ---- forward quantities of this ray
     for (int i = lane; i < c; i += WAVE) {
-        const int lin = lin_of(p, load_packed<PACKED>(vrow, i));
+        const int lin = lin_of<false>(p, load_packed<PACKED>(vrow, i));
         const float mu = acc[lin] - msgs[(size_t)r * M + i];
         const float e = expf(0 - fabsf(mu));
         const float sig = (mu > 0.0f ? 1.0f : e) / (1.0f + e);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(WAVE) void k_ray_bwd(Params p, int n, const float *
         const size_t off = (size_t)r * M + i;
         g_s[off] = g_s[off] + SB_[i];
         gm_row[i] = -mubar;
-        const int lin = lin_of(p, load_packed<PACKED>(vrow, i));
+        const int lin = lin_of<false>(p, load_packed<PACKED>(vrow, i));
         __hip_atomic_fetch_add(g_acc + lin, mubar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

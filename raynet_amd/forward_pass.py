@@ -335,11 +335,13 @@ class RayNetForwardPass(ForwardPass):
         dev = ctx.device
         bank = {v: f.to(dev, torch.float32).contiguous() for v, f in bank.items()}
         prior = self._prior()
-        G = ctx.grid_shape
+        # resident accumulators are flat buffers in the backend's own layout (4x4x4 bricks
+        # on the GPU, include/raynet_hip.h); `self.accumulator` is handed out as [gx][gy][gz]
+        G = ctx.acc_size()
         copies = ctx.acc_copies()
-        acc_in = torch.full(G, prior, dtype=torch.float32, device=dev)
-        acc_part = torch.zeros((copies,) + tuple(G), dtype=torch.float32, device=dev)
-        acc_next = torch.empty(G, dtype=torch.float32, device=dev)
+        acc_in = torch.full((G,), prior, dtype=torch.float32, device=dev)
+        acc_part = torch.zeros((copies, G), dtype=torch.float32, device=dev)
+        acc_next = torch.empty((G,), dtype=torch.float32, device=dev)
 
         # all camera matrices go up in ONE copy before the first launch: a pageable
         # host->device copy is a stream synchronisation point, and one per image would
@@ -457,7 +459,7 @@ class RayNetForwardPass(ForwardPass):
             else:
                 ctx.acc_combine(acc_part, prior, acc_next)
             acc_in, acc_next = acc_next, acc_in
-        self.accumulator = acc_in
+        self.accumulator = ctx.acc_to_grid(acc_in)
 
         # depth sweep: one launch over the scene (each image measures from its own camera
         # centre); maps are copied back asynchronously and handed out in order (the

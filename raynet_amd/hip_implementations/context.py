@@ -96,6 +96,22 @@ class HipContext(object):
     def acc_copies(self):
         return int(self.lib.rn_acc_copies(self._h))
 
+    # resident accumulators are 4x4x4-bricked (include/raynet_hip.h); the reference's
+    # [gx][gy][gz] view is produced / consumed through these two
+    def acc_size(self):
+        return int(self.lib.rn_acc_size(self._h))
+
+    def acc_to_grid(self, acc):
+        out = torch.empty(self.grid_shape, dtype=torch.float32, device=acc.device)
+        self._check(self.lib.rn_acc_to_grid(self._h, _ptr(acc), _ptr(out), _stream()))
+        return out
+
+    def acc_from_grid(self, grid):
+        grid = self.dev(grid, torch.float32).contiguous()
+        out = torch.zeros((self.acc_size(),), dtype=torch.float32, device=grid.device)
+        self._check(self.lib.rn_acc_from_grid(self._h, _ptr(grid), _ptr(out), _stream()))
+        return out
+
     # -- timing (bench.py): hipEvents on the stream the kernels run on ------
     def timer_start(self):
         self._check(self.lib.rn_timer_start(self._h, _stream()))

@@ -32,6 +32,13 @@ class OracleBackend(object):
     def acc_copies(self):
         return 1
 
+    # the stand-in keeps the reference's [gx][gy][gz] layout (flat)
+    def acc_size(self):
+        return int(np.prod(self.grid_shape))
+
+    def acc_to_grid(self, acc):
+        return acc.reshape(self.grid_shape).clone()
+
     @staticmethod
     def _unpack(vox):
         v = vox.numpy()
@@ -53,10 +60,11 @@ class OracleBackend(object):
         if first_sweep:
             msgs.zero_()
         m = np.ascontiguousarray(msgs.numpy())
-        out = np.ascontiguousarray(acc_part[0].numpy())
-        self.o.bp_sweep(Sr.numpy(), self._unpack(vox), rvc.numpy(), acc_in.numpy(), m, out)
+        out = np.ascontiguousarray(acc_part[0].numpy().reshape(self.grid_shape))
+        self.o.bp_sweep(Sr.numpy(), self._unpack(vox), rvc.numpy(),
+                        acc_in.numpy().reshape(self.grid_shape), m, out)
         msgs.numpy()[...] = m
-        acc_part[0].numpy()[...] = out
+        acc_part[0].numpy()[...] = out.ravel()
 
     def acc_reduce_local(self, acc_part, acc_out):
         acc_out.copy_(acc_part.sum(0))
@@ -71,7 +79,8 @@ class OracleBackend(object):
 
     def scene_depth(self, Sr, vox, rvc, acc, msgs, center, S_new, depth_map, rays_per_center=0):
         rvi = self._unpack(vox)
-        Sn = self.o.depth_distribution(Sr.numpy(), rvi, rvc.numpy(), acc.numpy(), msgs.numpy())
+        Sn = self.o.depth_distribution(Sr.numpy(), rvi, rvc.numpy(),
+                                       acc.numpy().reshape(self.grid_shape), msgs.numpy())
         if S_new is not None:
             S_new.numpy()[...] = Sn
         if depth_map is not None:

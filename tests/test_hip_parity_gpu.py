@@ -470,10 +470,12 @@ def test_resident_scene_path_equals_fused(torch, oracle_mod, case):
     for r in range(n):
         assert np.array_equal(vox_h[r, :rvc_h[r]], packed[r, :rvc_h[r]])
     prior_v = float(np.float32(np.log(0.05) - np.log(0.95)))
-    G = tuple(o.grid_shape)
-    acc_in = torch.full(G, prior_v, device=dev)
-    part = torch.zeros((ctx.acc_copies(),) + G, device=dev)
-    acc_next = torch.empty(G, device=dev)
+    # resident accumulators: flat, 4x4x4-bricked (rn_acc_size / rn_acc_to_grid / _from_grid)
+    Gb = ctx.acc_size()
+    assert Gb >= int(np.prod(o.grid_shape)) and Gb % 64 == 0
+    acc_in = torch.full((Gb,), prior_v, device=dev)
+    part = torch.zeros((ctx.acc_copies(), Gb), device=dev)
+    acc_next = torch.empty((Gb,), device=dev)
     msgs = torch.zeros((n, o.M), device=dev)
     acc_o = o.prior(0.05)
     msgs_o = np.zeros((n, o.M), np.float32)
@@ -486,10 +488,12 @@ def test_resident_scene_path_equals_fused(torch, oracle_mod, case):
         o.fused_bp(c["ray_idxs"], feats, c["P"], c["P_inv"], c["center"], vg, acc_o, msgs_o, out)
         acc_o = out
     assert np.all(np.abs(msgs.cpu().numpy() - msgs_o) <= logit_tol(msgs_o) * 8)
-    assert np.abs(acc_in.cpu().numpy() - acc_o).max() <= 5e-4
+    assert np.abs(ctx.acc_to_grid(acc_in).cpu().numpy() - acc_o).max() <= 5e-4
+    # grid -> bricks -> grid is the identity
+    assert np.array_equal(ctx.acc_to_grid(ctx.acc_from_grid(acc_o)).cpu().numpy(), acc_o)
     S_new = torch.zeros((n, o.M), device=dev)
     depth = torch.zeros((n,), device=dev)
-    ctx.scene_depth(Sr, vox, rvc, torch.from_numpy(acc_o).to(dev), torch.from_numpy(msgs_o).to(dev),
+    ctx.scene_depth(Sr, vox, rvc, ctx.acc_from_grid(acc_o), torch.from_numpy(msgs_o).to(dev),
                     cc, S_new, depth)
     _, _, S_new_o, depth_o = o.fused_depth(c["ray_idxs"], feats, c["P"], c["P_inv"], c["center"],
                                            vg, acc_o, msgs_o)
@@ -703,15 +707,15 @@ def test_box_scatter_equals_direct_sum(torch, oracle_mod, layout):
     packed = ((rvi[..., 0] << 20) | (rvi[..., 1] << 10) | rvi[..., 2]).astype(np.int32)
     G = tuple(grid)
     prior_v = float(np.float32(np.log(0.05) - np.log(0.95)))
-    acc_in = torch.full(G, prior_v, device="cuda")
+    acc_in = torch.full((ctx.acc_size(),), prior_v, device="cuda")
     outs = {}
     for patch_rows in (False, True):
-        part = torch.zeros((ctx.acc_copies(),) + G, device="cuda")
+        part = torch.zeros((ctx.acc_copies(), ctx.acc_size()), device="cuda")
         msgs = torch.zeros((n, M), device="cuda")
         ctx.scene_bp_sweep(torch.from_numpy(Sr).cuda(), torch.from_numpy(packed).cuda(),
                            torch.from_numpy(rvc).cuda(), acc_in, msgs, part, first_sweep=True,
                            patch_rows=patch_rows)
-        outs[patch_rows] = (part.sum(0).cpu().numpy(), msgs.cpu().numpy())
+        outs[patch_rows] = (ctx.acc_to_grid(part.sum(0)).cpu().numpy(), msgs.cpu().numpy())
     assert np.array_equal(outs[False][1], outs[True][1])           # same k_bp, same messages
     m = outs[True][1].astype(np.float64)
     truth = np.zeros(G, np.float64)
@@ -727,14 +731,14 @@ def test_box_scatter_equals_direct_sum(torch, oracle_mod, layout):
 def test_box_scatter_with_caller_made_voxel_lists(torch, oracle_mod):
     """Voxel lists that are NOT a DDA walk (random, repeated voxels): elements outside the
     tile's end-point box take the direct-atomic route; sums stay exact."""
-    M, D, grid = 32, 8, (16, 16, 16)
+    M, D, grid = 32, 8, (15, 16, 18)          # not multiples of the 4x4x4 brick
     from raynet_amd.hip_implementations import get_context
     ctx = get_context(M, D, 2, 4, 8, 8, 3, [-1, -1, -1, 1, 1, 1], grid)
     vg = oracle_mod.voxel_grid_centers(np.array([-1, -1, -1, 1, 1, 1], np.float32), grid)
     ctx.set_voxel_grid(torch.from_numpy(vg).cuda())
     rng = np.random.default_rng(3)
     n = 700                                   # not a multiple of the tile
-    rvi = rng.integers(0, 16, size=(n, M, 3)).astype(np.int32)
+    rvi = np.stack([rng.integers(0, g, size=(n, M)) for g in grid], -1).astype(np.int32)
     rvi[:50] = rvi[0]                          # many rays through identical voxels
     rvc = rng.integers(0, M + 1, size=n).astype(np.int32)
     Sr = rng.random((n, M)).astype(np.float32) + 0.01
@@ -742,8 +746,8 @@ def test_box_scatter_with_caller_made_voxel_lists(torch, oracle_mod):
     Sr /= np.maximum(Sr.sum(1, keepdims=True), 1e-30)
     packed = ((rvi[..., 0] << 20) | (rvi[..., 1] << 10) | rvi[..., 2]).astype(np.int32)
     G = tuple(grid)
-    acc_in = torch.full(G, -2.9, device="cuda")
-    part = torch.zeros((ctx.acc_copies(),) + G, device="cuda")
+    acc_in = torch.full((ctx.acc_size(),), -2.9, device="cuda")
+    part = torch.zeros((ctx.acc_copies(), ctx.acc_size()), device="cuda")
     msgs = torch.zeros((n, M), device="cuda")
     ctx.scene_bp_sweep(torch.from_numpy(Sr).cuda(), torch.from_numpy(packed).cuda(),
                        torch.from_numpy(rvc).cuda(), acc_in, msgs, part, first_sweep=True,
@@ -755,4 +759,5 @@ def test_box_scatter_with_caller_made_voxel_lists(torch, oracle_mod):
         if c > 1:
             np.add.at(truth, tuple(rvi[r, :c].T), m[r, :c])
     assert np.isfinite(m).all()
-    assert np.abs(part.sum(0).cpu().numpy() - truth).max() < 1e-5 * max(1.0, np.abs(truth).max())
+    got = ctx.acc_to_grid(part.sum(0)).cpu().numpy()
+    assert np.abs(got - truth).max() < 1e-5 * max(1.0, np.abs(truth).max())

@@ -1,14 +1,4 @@
 cd $GRAFT_REPO_ROOT
-run() { # label, flags, env...
-  label=$1; flags=$2; shift 2
-  env "$@" bash tools/ab_build.sh "$label" "$flags"
-}
-export RAYNET_HIP_SCATTER_MODE=2 RAYNET_RAY_TILE=16x16
-run "s16 cap4096      " "-DRN_BOX_STEPS=16"
-run "s16 cap2048      " "-DRN_BOX_STEPS=16 -DRN_BOX_CAP=2048"
-run "s16 cap1536      " "-DRN_BOX_STEPS=16 -DRN_BOX_CAP=1536"
-run "s8 cap1024       " "-DRN_BOX_STEPS=8 -DRN_BOX_CAP=1024"
-run "s16 r512 32x16   " "-DRN_BOX_STEPS=16 -DRN_BOX_RAYS=512 -DRN_BOX_CAP=4096" RAYNET_RAY_TILE=32x16
-run "s16 r512 16x32   " "-DRN_BOX_STEPS=16 -DRN_BOX_RAYS=512 -DRN_BOX_CAP=4096" RAYNET_RAY_TILE=16x32
-run "s16 r1024 32x32  " "-DRN_BOX_STEPS=16 -DRN_BOX_RAYS=1024 -DRN_BOX_CAP=6144" RAYNET_RAY_TILE=32x32
-run "s16 cap2048 nb16 " "-DRN_BOX_STEPS=16 -DRN_BOX_CAP=2048 -DRN_BOX_NB=16"
+run() { label=$1; flags=$2; shift 2; env "$@" bash tools/ab_build.sh "$label" "$flags"; }
+run "bricks        " ""
+run "bricks cap3072" "-DRN_BOX_CAP=3072"

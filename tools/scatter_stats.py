@@ -28,8 +28,8 @@ for r in range(5):
     Sr = torch.zeros((n, M), device="cuda")
     ctx.scene_prepare(ridx, [bank.view_features(scene, v) for v in views], P, Pi, cc, vox, rvc, Sr)
     msgs = torch.zeros((n, M), device="cuda")
-    acc = torch.full(grid, -2.94, device="cuda")
-    part = torch.zeros((1,) + grid, device="cuda")
+    acc = torch.full((ctx.acc_size(),), -2.94, device="cuda")
+    part = torch.zeros((ctx.acc_copies(), ctx.acc_size()), device="cuda")
     lib.rn_debug_scatter_stats(None, 1)
     ctx.scene_bp_sweep(Sr, vox, rvc, acc, msgs, part)
     torch.cuda.synchronize()
