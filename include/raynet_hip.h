@@ -179,22 +179,26 @@ int rn_fused_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float 
  * order (optional, may be NULL): a permutation of 0..n-1; wavefront i of the plane
  * sweep works on ray order[i].  It changes nothing but the schedule: walking the
  * rays along the direction of the epipolar lines keeps the neighbour views'
- * feature rows in L2. */
+ * feature rows in L2.
+ * ray_segments (optional scratch, may be NULL): [n][8] f32; the traversal leaves every
+ * ray's bbox entry / exit point there and the plane sweep reads it back instead of
+ * repeating the double-precision back-projection (sampling_schemes.cu:44-90) per wavefront. */
 int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
                      const float *const *features_views_host, const float *P,
                      const float *P_inv, const float *camera_center, const int32_t *order,
-                     int32_t *vox, int32_t *rvc, float *Sr, void *stream);
+                     int32_t *vox, int32_t *rvc, float *Sr, float *ray_segments, void *stream);
 
 /* The same for ALL reference images of a scene in two launches (one grid row per image).
  * Image g owns rows [g*rows_per_image, g*rows_per_image + n) of vox / rvc / Sr; all images
  * share ray_idxs [n] and the optional schedule `order` [n].
  *   cameras        [n_images][12N + 12 + 4] f32: P of the N views, P_inv and camera centre
  *                  of the reference view (device)
- *   features_views [n_images][N] device pointers, stored in DEVICE memory */
+ *   features_views [n_images][N] device pointers, stored in DEVICE memory
+ *   ray_segments   optional scratch [n_images * rows_per_image][8] f32 (see above) */
 int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_per_image,
                          const int32_t *ray_idxs, const float *const *features_views,
                          const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
-                         float *Sr, void *stream);
+                         float *Sr, float *ray_segments, void *stream);
 
 /* Accumulators of the resident path are stored as 4x4x4 bricks,
  * [ceil(gx/4)][ceil(gy/4)][ceil(gz/4)][4][4][4] f32 = rn_acc_size() floats (a ray stays

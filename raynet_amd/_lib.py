@@ -80,8 +80,8 @@ SIGNATURES = {
     "rn_mvcnn_voxel_space_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "rn_fused_bp_sweep": [_P, _I] + [_P] * 13,
     "rn_fused_depth": [_P, _I] + [_P] * 12,
-    "rn_scene_prepare": [_P, _I, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P],
-    "rn_scene_prepare_all": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_scene_prepare": [_P, _I, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_scene_prepare_all": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "rn_acc_copies": [_P],
     "rn_acc_size": [_P],
     "rn_acc_to_grid": [_P, _P, _P, _P],

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                                                    const float *__restrict__ starts,
                                                    const float *__restrict__ ends, int32_t *vox,
                                                    int32_t *rvc, int cam_stride,
-                                                   int64_t rows_per_image) {
+                                                   int64_t rows_per_image, float *seg_out) {
     __shared__ int32_t tile[WAVE * (TRAV_TILE + 1)];
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * WAVE;
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
         cc += (size_t)g * cam_stride;
         vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
         rvc += (size_t)g * rows_per_image;
+        if (seg_out) seg_out += (size_t)g * rows_per_image * 8;
     }
     const int r = r0 + lane;
     const bool live = r < n;
@@ -154,6 +155,12 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                 s[i] = starts[3 * r + i];
                 e[i] = ends[3 * r + i];
             }
+        }
+        // the plane sweep (one wavefront per ray) reads the segment back instead of repeating
+        // the double-precision back-projection 64 lanes wide
+        if (seg_out) {
+            reinterpret_cast<float4 *>(seg_out)[2 * (size_t)r] = make_float4(s[0], s[1], s[2], 0.f);
+            reinterpret_cast<float4 *>(seg_out)[2 * (size_t)r + 1] = make_float4(e[0], e[1], e[2], 0.f);
         }
     }
     // ---- DDA set-up (ray_tracing.pyx:99-161), identical arithmetic to rn::dda
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
     const int32_t *__restrict__ vox, const int32_t *__restrict__ rvc, float *S_planes,
     float *S_voxel, float *depth_from_planes, float *points,
     const int32_t *__restrict__ order, const float *const *__restrict__ fv_table, int cam_stride,
-    int64_t rows_per_image) {
+    int64_t rows_per_image, const float *__restrict__ seg) {
     if (rows_per_image > 0) {       // blockIdx.y = reference image of a scene-wide launch
         const int g = blockIdx.y;
         P += (size_t)g * cam_stride;
@@ -279,6 +286,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
         vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
         rvc += (size_t)g * rows_per_image;
         S_voxel += (size_t)g * rows_per_image * p.M;
+        if (seg) seg += (size_t)g * rows_per_image * 8;
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int naxes = p.gx + p.gy + p.gz;
@@ -296,7 +304,12 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
     if (order) r = uniform(order[r]);      // schedule only: which ray this wavefront takes
 
     float s[3], e[3];
-    if (ray_idxs) {
+    if (seg) {                      // k_traverse's endpoints of this very row (same arithmetic)
+        const float4 a = reinterpret_cast<const float4 *>(seg)[2 * (size_t)r];
+        const float4 b = reinterpret_cast<const float4 *>(seg)[2 * (size_t)r + 1];
+        s[0] = a.x; s[1] = a.y; s[2] = a.z;
+        e[0] = b.x; e[1] = b.y; e[2] = b.z;
+    } else if (ray_idxs) {
         sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
     } else {
 #pragma unroll
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
         else
             sweep_coop<NV, LPS>(p, fv, fv_table, P, s, e, lane, Sl);
         wave_sync();
-        softmax_column(p.D, lane, Sl);
+        softmax_column<MAPMODE == 2>(p.D, lane, Sl);
     }
     wave_sync();
 
@@ -361,18 +374,22 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
     const int count = min(uniform(rvc[r]), p.M);
     const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
     float *out = S_voxel + (size_t)r * p.M;
-    const float srsum = map_planes_to_voxels<PACKED>(p, axes, vrow, count, s, e, Sl, vals, lane);
+    // MAPMODE 2 = the resident path: value-only divisions through the hardware reciprocal
+    // (the plane index walk inside stays IEEE); MAPMODE 1 = K6 / K11, reference arithmetic
+    const float srsum =
+        map_planes_to_voxels<PACKED, MAPMODE == 2>(p, axes, vrow, count, s, e, Sl, vals, lane);
     if (MAPMODE == 1) {
         for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
     } else {
         float sum = 0.0f;
+        const float rs = __builtin_amdgcn_rcpf(srsum);
         for (int i = lane; i < count; i += WAVE) {
-            const float v = clampf(vals[i] / srsum, (float)1e-5, (float)(1 - 1e-5));
+            const float v = clampf(vals[i] * rs, (float)1e-5, (float)(1 - 1e-5));
             vals[i] = v;
             sum += v;
         }
-        sum = wave_sum(sum);
-        for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / sum;
+        sum = __builtin_amdgcn_rcpf(wave_sum(sum));
+        for (int i = lane; i < count; i += WAVE) out[i] = vals[i] * sum;
     }
 }
 
@@ -1300,6 +1317,7 @@ struct SweepArgs {
     int cam_stride = 0;
     int64_t rows_per_image = 0;
     int n_images = 1;
+    const float *seg = nullptr;     // [rows][8]: ray segments written by k_traverse
 };
 
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
@@ -1309,7 +1327,7 @@ void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
                        dim3(ray_blocks(a.n), a.n_images), dim3(BLOCK), sweep_lds(ctx->p), st,
                        ctx->p, a.n, a.ray_idxs, a.fv, a.P, a.P_inv, a.cc, a.starts, a.ends, a.S_in,
                        ctx->axes, a.vox, a.rvc, a.S_planes, a.S_voxel, a.depth_from_planes,
-                       a.points, a.order, a.fv_table, a.cam_stride, a.rows_per_image);
+                       a.points, a.order, a.fv_table, a.cam_stride, a.rows_per_image, a.seg);
 }
 
 // pick the plane-sweep flavour: cooperative for F=32 and 2..9 views, generic otherwise
@@ -1567,7 +1585,8 @@ int rn_voxel_traversal(rn_ctx *ctx, int32_t n, const float *ray_start, const flo
         ProfScope prof(ctx, RN_K_TRAVERSE, n, S(stream));
         hipLaunchKernelGGL((k_traverse<false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, S(stream),
                            ctx->p, n, (const int32_t *)nullptr, (const float *)nullptr,
-                           (const float *)nullptr, ray_start, ray_end, rvi, rvc, 0, (int64_t)0);
+                           (const float *)nullptr, ray_start, ray_end, rvi, rvc, 0, (int64_t)0,
+                           (float *)nullptr);
     }
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
@@ -1648,7 +1667,7 @@ static int prefix_api(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const flo
         ProfScope prof(ctx, RN_K_TRAVERSE, n, st);
         hipLaunchKernelGGL((k_traverse<false>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, st, ctx->p,
                            n, ray_idxs, P_inv, cc, (const float *)nullptr, (const float *)nullptr,
-                           rvi, rvc, 0, (int64_t)0);
+                           rvi, rvc, 0, (int64_t)0, (float *)nullptr);
     }
     RN_LAUNCH_CHECK(ctx);
     SweepArgs a{n, ray_idxs, stacked_views(ctx->p, features), P, P_inv, cc, nullptr, nullptr,
@@ -1750,7 +1769,7 @@ int rn_acc_from_grid(rn_ctx *ctx, const float *grid, float *acc_out, void *strea
 int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
                      const float *const *features_views_host, const float *P, const float *P_inv,
                      const float *camera_center, const int32_t *order, int32_t *vox, int32_t *rvc,
-                     float *Sr, void *stream) {
+                     float *Sr, float *ray_segments, void *stream) {
     if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !ray_idxs || !features_views_host || !P || !P_inv || !camera_center ||
         !vox || !rvc || !Sr)
@@ -1766,12 +1785,13 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
         ProfScope prof(ctx, RN_K_TRAVERSE, n, S(stream));
         hipLaunchKernelGGL((k_traverse<true>), dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, S(stream),
                            ctx->p, n, ray_idxs, P_inv, camera_center, (const float *)nullptr,
-                           (const float *)nullptr, vox, rvc, 0, (int64_t)0);
+                           (const float *)nullptr, vox, rvc, 0, (int64_t)0, ray_segments);
     }
     RN_LAUNCH_CHECK(ctx);
     SweepArgs a{n, ray_idxs, fv, P, P_inv, camera_center, nullptr, nullptr, nullptr, vox, rvc,
                 nullptr, Sr, nullptr, nullptr};
     a.order = order;
+    a.seg = ray_segments;
     launch_sweep<2, true>(ctx, a, true, S(stream));
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
@@ -1780,7 +1800,7 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
 int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_per_image,
                          const int32_t *ray_idxs, const float *const *features_views,
                          const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
-                         float *Sr, void *stream) {
+                         float *Sr, float *ray_segments, void *stream) {
     if (!ctx || n_images < 1 || n < 0 || rows_per_image < n || !ray_idxs || !features_views ||
         !cameras || !vox || !rvc || !Sr)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -1794,7 +1814,8 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
         ProfScope prof(ctx, RN_K_TRAVERSE, n * n_images, S(stream));
         hipLaunchKernelGGL((k_traverse<true>), dim3((n + WAVE - 1) / WAVE, n_images), dim3(WAVE), 0,
                            S(stream), ctx->p, n, ray_idxs, P_inv, cc, (const float *)nullptr,
-                           (const float *)nullptr, vox, rvc, cam_stride, rows_per_image);
+                           (const float *)nullptr, vox, rvc, cam_stride, rows_per_image,
+                           ray_segments);
     }
     RN_LAUNCH_CHECK(ctx);
     SweepArgs a{n, ray_idxs, FeatureViews{}, P, P_inv, cc, nullptr, nullptr, nullptr, vox, rvc,
@@ -1804,6 +1825,7 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
     a.cam_stride = cam_stride;
     a.rows_per_image = rows_per_image;
     a.n_images = n_images;
+    a.seg = ray_segments;
     launch_sweep<2, true>(ctx, a, true, S(stream));
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;

@@ -275,19 +275,39 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
     }
 }
 
+// a / b for VALUE arithmetic only (never feeds an index): hardware reciprocal when FAST
+template <bool FAST>
+__device__ __forceinline__ float vdiv(float a, float b) {
+    return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b;
+}
+// expf(x) for x <= 0: the library's own sequence (extended-precision x*log2(e), v_exp_f32,
+// ldexp, underflow select) minus its overflow select and range constants -- x <= 0 cannot
+// overflow.  Bit-identical to expf for every x <= 0, including -inf (0) and NaN.
+__device__ __forceinline__ float exp_nonpos(float x) {
+    const float log2e_hi = 0x1.715476p+0f, log2e_lo = 0x1.4ae0bep-26f;   // 0x3fb8aa3b, 0x32a5705f
+    const float ph = x * log2e_hi;
+    float pl = __builtin_fmaf(x, log2e_hi, -ph);
+    pl = __builtin_fmaf(x, log2e_lo, pl);
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+    const float r = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+    return x < -0x1.9d1da00000000p+6f ? 0.0f : r;       // 0xc2ce8ed0, the library's underflow bound
+}
 // feature_similarities.cu:109-123 on the LDS column
+template <bool FAST = false>
 __device__ __forceinline__ void softmax_column(int D, int lane, float *Sl) {
     float mx = -INFINITY;
     for (int k = lane; k < D; k += WAVE) mx = fmaxf(mx, Sl[k]);
     mx = wave_max(mx);
     float sum = 0.0f;
     for (int k = lane; k < D; k += WAVE) {
-        const float v = expf(Sl[k] - mx);
+        const float d = Sl[k] - mx;
+        const float v = d <= 0.0f ? exp_nonpos(d) : expf(d);     // d > 0 only for NaN / inf input
         Sl[k] = v;
         sum += v;
     }
     sum = wave_sum(sum);
-    for (int k = lane; k < D; k += WAVE) Sl[k] = Sl[k] / sum;
+    for (int k = lane; k < D; k += WAVE) Sl[k] = vdiv<FAST>(Sl[k], sum);
 }
 
 // ------------------------------------------------------------------- a3
@@ -319,7 +339,7 @@ __device__ __forceinline__ int pack_voxel(int x, int y, int z) {
 //     evaluated with the same fp32 expressions, so the plane indices are exact;
 //   * vals[] (LDS, M floats) receives the un-normalised interpolation, the sum
 //     is returned wave-uniform.
-template <bool PACKED>
+template <bool PACKED, bool FAST = false>
 __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
                                                       const float *__restrict__ axes,
                                                       const int32_t *__restrict__ vrow,
@@ -364,8 +384,8 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
             const int right = left + 1;
             float left_d = fabsf(t - (0.0f + left * step));
             float right_d = fabsf(t - (0.0f + right * step));
-            const float c1 = 1.0f - (left_d / (left_d + right_d));
-            const float c2 = 1.0f - (right_d / (left_d + right_d));
+            const float c1 = 1.0f - vdiv<FAST>(left_d, left_d + right_d);
+            const float c2 = 1.0f - vdiv<FAST>(right_d, left_d + right_d);
             val = c1 * Sl[left] + c2 * Sl[right];
             vals[i] = val;
         }
@@ -389,19 +409,6 @@ __device__ __forceinline__ float bp_log(float x) {
 __device__ __forceinline__ float bp_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float bp_log(float x) { return logf(x); }
 #endif
-// expf(x) for x <= 0: the library's own sequence (extended-precision x*log2(e), v_exp_f32,
-// ldexp, underflow select) minus its overflow select and range constants -- x <= 0 cannot
-// overflow.  Bit-identical to expf for every x <= 0, including -inf (0) and NaN.
-__device__ __forceinline__ float exp_nonpos(float x) {
-    const float log2e_hi = 0x1.715476p+0f, log2e_lo = 0x1.4ae0bep-26f;   // 0x3fb8aa3b, 0x32a5705f
-    const float ph = x * log2e_hi;
-    float pl = __builtin_fmaf(x, log2e_hi, -ph);
-    pl = __builtin_fmaf(x, log2e_lo, pl);
-    const float e = __builtin_rintf(ph);
-    const float a = (ph - e) + pl;
-    const float r = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
-    return x < -0x1.9d1da00000000p+6f ? 0.0f : r;       // 0xc2ce8ed0, the library's underflow bound
-}
 __device__ __forceinline__ float occupancy_to_ray(float acc, float msg) {
     // mrf_bp.cu:12-35
     // t1 = exp(0 - max(0,mu)), t2 = exp(mu - max(0,mu)): one of the two is exp(0) = 1

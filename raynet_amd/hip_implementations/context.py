@@ -238,13 +238,22 @@ class HipContext(object):
             _ptr(depth_map), _stream()))
 
     # -- resident-scene path ---------------------------------------------------
+    def _segments(self, rows):
+        """Scratch for the rays' bbox entry / exit points ([rows][8] f32), kept per context."""
+        seg = getattr(self, "_seg_scratch", None)
+        if seg is None or seg.shape[0] < rows:
+            seg = torch.empty((rows, 8), dtype=torch.float32, device=self.device)
+            self._seg_scratch = seg
+        return seg
+
     def scene_prepare(self, ray_idxs, feature_views, P, P_inv, center, vox, rvc, Sr, order=None):
         assert len(feature_views) == self.N
         assert order is None or (order.dtype == torch.int32 and len(order) == len(ray_idxs))
         arr = (ctypes.c_void_p * self.N)(*[fv.data_ptr() for fv in feature_views])
         self._check(self.lib.rn_scene_prepare(self._h, len(ray_idxs), _ptr(ray_idxs), arr, _ptr(P),
                                               _ptr(P_inv), _ptr(center), _ptr(order), _ptr(vox),
-                                              _ptr(rvc), _ptr(Sr), _stream()))
+                                              _ptr(rvc), _ptr(Sr),
+                                              _ptr(self._segments(len(ray_idxs))), _stream()))
 
     def scene_prepare_all(self, n_images, rows_per_image, ray_idxs, feature_table, cameras, vox,
                           rvc, Sr, order=None):
@@ -258,7 +267,7 @@ class HipContext(object):
         self._check(self.lib.rn_scene_prepare_all(
             self._h, int(n_images), len(ray_idxs), int(rows_per_image), _ptr(ray_idxs),
             _ptr(feature_table), _ptr(cameras), _ptr(order), _ptr(vox), _ptr(rvc), _ptr(Sr),
-            _stream()))
+            _ptr(self._segments(int(n_images) * int(rows_per_image))), _stream()))
 
     def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False,
                        patch_rows=False):
