@@ -897,31 +897,30 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
 // ------------------------------------------------- accumulator scatter, LDS box
 // A tile of BOX_RAYS neighbouring rays x BOX_STEPS steps covers a compact block of the grid
 // in which every voxel is hit by ~10-20 of the tile's rays (ray spacing << voxel size).
-// The tile's messages are therefore summed in a dense LDS image of its bounding box
+// The tile's messages are therefore summed in a dense LDS image of their bounding box
 // in DOUBLE (measured, tools/lds_atomic_bench.hip: ds_add_f64 runs at ~1.7 T lane-ops/s,
 // ds_add_f32 at 0.2 T/s whatever the addresses; the sums also become order-independent to
-// ~1e-16, i.e. the accumulator is reproducible run to run) and the box is flushed once,
-// z-fastest, so that the global atomics of one instruction fall into a few 64-byte segments
-// and there is one per DISTINCT voxel of the tile instead of one per (ray, voxel).
-// The box comes from the first / last voxel of every ray segment (a DDA list is monotone
-// along each axis); an element outside it -- arbitrary caller-made lists -- or a tile whose
-// box exceeds the LDS budget goes straight to the global atomic: always correct.
+// ~1e-16, i.e. the accumulator is reproducible run to run) and the box is flushed once, so
+// there is one global atomic per DISTINCT voxel of the tile instead of one per (ray, voxel).
+// One workgroup walks a tile chunk by chunk: all of a chunk's (message, voxel) pairs sit in
+// registers (BOX_NB per thread, one round trip), the box is the exact bounding box of those
+// voxels -- no assumption on the lists -- and a chunk whose box exceeds the LDS budget (rows
+// that are not patch-ordered) goes straight to the global atomics: always correct.
 #ifndef RN_BOX_STEPS
-#define RN_BOX_STEPS 16
-#endif
-#ifndef RN_BOX_RAYS
-#define RN_BOX_RAYS 256
+#define RN_BOX_STEPS 32      // 128 B of every row per round trip: whole cache lines
 #endif
 #ifndef RN_BOX_CAP
-#define RN_BOX_CAP 2048
+#define RN_BOX_CAP 4096
 #endif
-#ifndef RN_BOX_NB
-#define RN_BOX_NB 16
+#ifndef RN_BOX_RAYS
+#define RN_BOX_RAYS 128      // half a 16x16 patch
 #endif
-constexpr int BOX_NB = RN_BOX_NB;
 constexpr int BOX_STEPS = RN_BOX_STEPS;
 constexpr int BOX_RAYS = RN_BOX_RAYS;
-constexpr int BOX_CAP = RN_BOX_CAP;      // voxels (doubles of LDS) per tile
+constexpr int BOX_CAP = RN_BOX_CAP;      // voxels (doubles of LDS) per chunk
+constexpr int BOX_NB = BOX_RAYS * BOX_STEPS / BLOCK;     // pairs per thread and chunk
+__device__ __forceinline__ int wave_reduce_max(int x) { return lane63i(wave_scan_max(x)); }
+__device__ __forceinline__ int wave_reduce_min(int x) { return ~wave_reduce_max(~x); }
 template <bool PACKED>
 __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                                        const float *__restrict__ msgs,
@@ -929,133 +928,72 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                                        const int32_t *__restrict__ rvc,
                                                        float *acc_out, int64_t xcd_stride) {
     __shared__ double box[BOX_CAP];
-    __shared__ int red[6 * WAVES_PER_BLOCK];
+    __shared__ int red[2][6 * WAVES_PER_BLOCK];
+    __shared__ int red_cnt[WAVES_PER_BLOCK];
     __shared__ int cnts[BOX_RAYS];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
-    const int nchunks = (p.M + BOX_STEPS - 1) / BOX_STEPS;
-    const int lb = xcd_block(blockIdx.x, gridDim.x);
-    const int r0 = (lb / nchunks) * BOX_RAYS;
-    const int s0 = (lb % nchunks) * BOX_STEPS;
+    const int r0 = xcd_block(blockIdx.x, gridDim.x) * BOX_RAYS;
     if (xcd_stride) {
         const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
         acc_out += xcc * xcd_stride;
     }
-    const size_t vstride = PACKED ? 1 : 3;
-    // ---- bounding box of the tile's segments
-    int lo0 = 1 << 30, lo1 = 1 << 30, lo2 = 1 << 30, hi0 = -1, hi1 = -1, hi2 = -1;
+    // a wavefront instruction covers RPI rays x BOX_STEPS steps; thread (sub, col) of wave w
+    // owns step col of the rays w*RPI + sub + k*STRIDE
+    constexpr int RPI = WAVE / BOX_STEPS;
+    constexpr int STRIDE = WAVES_PER_BLOCK * RPI;
+    const int sub = lane / BOX_STEPS, col = lane % BOX_STEPS;
+    const int j0 = w * RPI + sub;
+    int maxc = 0;
     for (int j = tid; j < BOX_RAYS; j += BLOCK) {
-        const int r = r0 + j;
-        int cnt = r < n ? min(rvc[r], p.M) : 0;
-        if (cnt <= 1) cnt = 0;        // such rays send no message (mrf_np.py:300)
-        cnts[j] = cnt;
-        if (s0 < cnt) {
-            const int32_t *vrow = vox + (size_t)r * p.M * vstride;
-            int x, y, z;
-            load_voxel<PACKED>(vrow, s0, x, y, z);
-            lo0 = min(lo0, x); hi0 = max(hi0, x);
-            lo1 = min(lo1, y); hi1 = max(hi1, y);
-            lo2 = min(lo2, z); hi2 = max(hi2, z);
-            load_voxel<PACKED>(vrow, min(cnt, s0 + BOX_STEPS) - 1, x, y, z);
-            lo0 = min(lo0, x); hi0 = max(hi0, x);
-            lo1 = min(lo1, y); hi1 = max(hi1, y);
-            lo2 = min(lo2, z); hi2 = max(hi2, z);
+        int c = r0 + j < n ? min(rvc[r0 + j], p.M) : 0;
+        if (c <= 1) c = 0;            // such rays send no message (mrf_np.py:300)
+        cnts[j] = c;
+        maxc = max(maxc, c);
+    }
+    maxc = wave_reduce_max(maxc);
+    if (lane == 0) red_cnt[w] = maxc;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WAVES_PER_BLOCK; k++) maxc = max(maxc, red_cnt[k]);
+    maxc = uniform(maxc);
+
+    int it = 0;
+    // per-thread partial bounding box -> the workgroup's (uniform)
+    auto block_bbox = [&](int &lo0, int &lo1, int &lo2, int &hi0, int &hi1, int &hi2) {
+        lo0 = wave_reduce_min(lo0); lo1 = wave_reduce_min(lo1); lo2 = wave_reduce_min(lo2);
+        hi0 = wave_reduce_max(hi0); hi1 = wave_reduce_max(hi1); hi2 = wave_reduce_max(hi2);
+        int *rd = red[it++ & 1];
+        if (lane == 0) {
+            rd[w] = lo0; rd[WAVES_PER_BLOCK + w] = lo1; rd[2 * WAVES_PER_BLOCK + w] = lo2;
+            rd[3 * WAVES_PER_BLOCK + w] = hi0; rd[4 * WAVES_PER_BLOCK + w] = hi1;
+            rd[5 * WAVES_PER_BLOCK + w] = hi2;
         }
-    }
+        __syncthreads();              // also: every thread has finished the previous flush
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo0 = min(lo0, __shfl_xor(lo0, o)); hi0 = max(hi0, __shfl_xor(hi0, o));
-        lo1 = min(lo1, __shfl_xor(lo1, o)); hi1 = max(hi1, __shfl_xor(hi1, o));
-        lo2 = min(lo2, __shfl_xor(lo2, o)); hi2 = max(hi2, __shfl_xor(hi2, o));
-    }
-    if (lane == 0) {
-        red[w] = lo0; red[WAVES_PER_BLOCK + w] = lo1; red[2 * WAVES_PER_BLOCK + w] = lo2;
-        red[3 * WAVES_PER_BLOCK + w] = hi0; red[4 * WAVES_PER_BLOCK + w] = hi1;
-        red[5 * WAVES_PER_BLOCK + w] = hi2;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < WAVES_PER_BLOCK; k++) {
-        lo0 = min(lo0, red[k]); lo1 = min(lo1, red[WAVES_PER_BLOCK + k]);
-        lo2 = min(lo2, red[2 * WAVES_PER_BLOCK + k]);
-        hi0 = max(hi0, red[3 * WAVES_PER_BLOCK + k]); hi1 = max(hi1, red[4 * WAVES_PER_BLOCK + k]);
-        hi2 = max(hi2, red[5 * WAVES_PER_BLOCK + k]);
-    }
-    lo0 = uniform(lo0); lo1 = uniform(lo1); lo2 = uniform(lo2);
-    hi0 = uniform(hi0); hi1 = uniform(hi1); hi2 = uniform(hi2);
-    if (hi0 < 0) return;              // no ray of the tile reaches this chunk
-#if defined(RN_BOX_SKIP) && (RN_BOX_SKIP & 4)
-    return;
-#endif
-    const int d0 = hi0 - lo0 + 1, d1 = hi1 - lo1 + 1, d2 = hi2 - lo2 + 1;
-    const int V = d0 * d1 * d2;
-    const bool dense = V <= BOX_CAP;
-    if (dense)
-        for (int i = tid; i < V; i += BLOCK) box[i] = 0.0;
-    __syncthreads();
-#ifdef RN_SCATTER_STATS
-    if (tid == 0) {
-        atomicAdd(&g_scatter_stats[0], 1ull);
-        atomicAdd(&g_scatter_stats[1], dense ? 1ull : 0ull);
-        atomicAdd(&g_scatter_stats[2], (unsigned long long)V);
-    }
-#endif
-    // ---- contributions: a wavefront instruction covers WAVE / BOX_STEPS rays x BOX_STEPS steps;
-    // BOX_NB instructions' loads are in flight before the first LDS add
-    {
-        constexpr int RPI = WAVE / BOX_STEPS;
-        constexpr int STRIDE = WAVES_PER_BLOCK * RPI;
-        constexpr int NB = BOX_NB;
-        const int sub = lane / BOX_STEPS, col = lane % BOX_STEPS;
-        const int st = s0 + col;
-        for (int j0 = w * RPI + sub; j0 < BOX_RAYS; j0 += STRIDE * NB) {
-            float m[NB];
-            int x[NB], y[NB], z[NB];
-            bool ok[NB];
-#pragma unroll
-            for (int k = 0; k < NB; k++) {
-                const int j = j0 + k * STRIDE;
-                ok[k] = j < BOX_RAYS && st < cnts[min(j, BOX_RAYS - 1)];
-                // rows of padding / short rays are read at the tile's first row: valid memory
-                const int rr = ok[k] ? r0 + j : r0, ss = ok[k] ? st : 0;
-                m[k] = msgs[(size_t)rr * p.M + ss];
-                load_voxel<PACKED>(vox + (size_t)rr * p.M * vstride, ss, x[k], y[k], z[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < NB; k++) {
-                if (!ok[k]) continue;
-                const unsigned ux = x[k] - lo0, uy = y[k] - lo1, uz = z[k] - lo2;
-                if (dense && ux < (unsigned)d0 && uy < (unsigned)d1 && uz < (unsigned)d2) {
-#if defined(RN_BOX_SKIP) && (RN_BOX_SKIP & 1)
-                    asm volatile("" ::"v"((ux * d1 + uy) * d2 + uz), "v"(m[k]));
-#else
-                    __hip_atomic_fetch_add(box + (ux * d1 + uy) * d2 + uz, (double)m[k],
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-                } else {
-                    __hip_atomic_fetch_add(acc_out + lin_xyz<PACKED>(p, x[k], y[k], z[k]), m[k],
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+        for (int k = 0; k < WAVES_PER_BLOCK; k++) {
+            lo0 = min(lo0, rd[k]); lo1 = min(lo1, rd[WAVES_PER_BLOCK + k]);
+            lo2 = min(lo2, rd[2 * WAVES_PER_BLOCK + k]);
+            hi0 = max(hi0, rd[3 * WAVES_PER_BLOCK + k]);
+            hi1 = max(hi1, rd[4 * WAVES_PER_BLOCK + k]);
+            hi2 = max(hi2, rd[5 * WAVES_PER_BLOCK + k]);
         }
-    }
-    if (!dense) return;
-#if defined(RN_BOX_SKIP) && (RN_BOX_SKIP & 2)
-    return;
-#endif
-    __syncthreads();
-    // ---- flush, z fastest; (i0, i1, i2) advance by BLOCK elements without divisions
-    {
+        lo0 = uniform(lo0); lo1 = uniform(lo1); lo2 = uniform(lo2);
+        hi0 = uniform(hi0); hi1 = uniform(hi1); hi2 = uniform(hi2);
+    };
+    // box -> accumulator, z fastest; (i0, i1, i2) advance by BLOCK elements without divisions
+    auto flush_box = [&](int lo0, int lo1, int lo2, int d0, int d1, int d2) {
+        const int V = d0 * d1 * d2;
         int i2 = tid % d2, t = tid / d2;
         int i1 = t % d1, i0 = t / d1;
         const int sz = BLOCK % d2, ty = BLOCK / d2;
         const int sy = ty % d1, sx = ty / d1;
         for (int i = tid; i < V; i += BLOCK) {
-            const float v = (float)box[i];
-            if (v != 0.0f) {
+            const float val = (float)box[i];
+            if (val != 0.0f) {
 #ifdef RN_SCATTER_STATS
                 atomicAdd(&g_scatter_stats[3], 1ull);
 #endif
-                __hip_atomic_fetch_add(acc_out + lin_xyz<PACKED>(p, lo0 + i0, lo1 + i1, lo2 + i2), v,
+                __hip_atomic_fetch_add(acc_out + lin_xyz<PACKED>(p, lo0 + i0, lo1 + i1, lo2 + i2), val,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             i2 += sz;
@@ -1063,6 +1001,108 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             i1 += sy;
             if (i1 >= d1) { i1 -= d1; i0++; }
             i0 += sx;
+        }
+    };
+    for (int s0 = 0; s0 < maxc; s0 += BOX_STEPS) {
+        const int st = s0 + col;
+        // ---- this chunk's pairs into registers, and their bounding box
+        float m[BOX_NB];
+        int v[BOX_NB];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int k = 0; k < BOX_NB; k++) {
+            const bool ok = st < cnts[j0 + k * STRIDE];
+            okmask |= (unsigned)ok << k;
+            // rows of padding / short rays are read at the tile's first row: valid memory
+            const int rr = ok ? r0 + j0 + k * STRIDE : r0, ss = ok ? st : 0;
+            m[k] = msgs[(size_t)rr * p.M + ss];
+            v[k] = load_packed<PACKED>(vox + (size_t)rr * p.M * (PACKED ? 1 : 3), ss);
+        }
+        int lo0 = 1 << 30, lo1 = 1 << 30, lo2 = 1 << 30, hi0 = -1, hi1 = -1, hi2 = -1;
+#pragma unroll
+        for (int k = 0; k < BOX_NB; k++) {
+            if (okmask >> k & 1) {
+                const int x = v[k] >> 20, y = (v[k] >> 10) & 1023, z = v[k] & 1023;
+                lo0 = min(lo0, x); hi0 = max(hi0, x);
+                lo1 = min(lo1, y); hi1 = max(hi1, y);
+                lo2 = min(lo2, z); hi2 = max(hi2, z);
+            }
+        }
+        block_bbox(lo0, lo1, lo2, hi0, hi1, hi2);
+        if (hi0 < 0) continue;        // (cannot happen below maxc; uniform anyway)
+        const int d0 = hi0 - lo0 + 1, d1 = hi1 - lo1 + 1, d2 = hi2 - lo2 + 1;
+        const int V = d0 * d1 * d2;
+#ifdef RN_SCATTER_STATS
+        if (tid == 0) {
+            atomicAdd(&g_scatter_stats[0], 1ull);
+            atomicAdd(&g_scatter_stats[1], V <= BOX_CAP ? 1ull : 0ull);
+            atomicAdd(&g_scatter_stats[2], (unsigned long long)V);
+        }
+#endif
+        if (V <= BOX_CAP) {
+            for (int i = tid; i < V; i += BLOCK) box[i] = 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BOX_NB; k++)
+                if (okmask >> k & 1) {
+                    const int x = v[k] >> 20, y = (v[k] >> 10) & 1023, z = v[k] & 1023;
+                    __hip_atomic_fetch_add(box + ((x - lo0) * d1 + (y - lo1)) * d2 + (z - lo2),
+                                           (double)m[k], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            __syncthreads();
+            flush_box(lo0, lo1, lo2, d0, d1, d2);
+            continue;
+        }
+        // ---- too big for LDS (rows that are not patch-ordered, very oblique bundles): the
+        // chunk again in quarters, pairs re-read (L2-hot) so that this rare path costs the
+        // common one no registers; a quarter that still does not fit takes the direct atomics
+#pragma unroll 1
+        for (int ca = 0; ca < BOX_STEPS; ca += BOX_STEPS / 4) {
+            const bool mine = col >= ca && col < ca + BOX_STEPS / 4;
+            lo0 = lo1 = lo2 = 1 << 30;
+            hi0 = hi1 = hi2 = -1;
+#pragma unroll 1
+            for (int k = 0; k < BOX_NB; k++) {
+                const int j = j0 + k * STRIDE;
+                if (mine && st < cnts[j]) {
+                    const int pv = load_packed<PACKED>(
+                        vox + (size_t)(r0 + j) * p.M * (PACKED ? 1 : 3), st);
+                    const int x = pv >> 20, y = (pv >> 10) & 1023, z = pv & 1023;
+                    lo0 = min(lo0, x); hi0 = max(hi0, x);
+                    lo1 = min(lo1, y); hi1 = max(hi1, y);
+                    lo2 = min(lo2, z); hi2 = max(hi2, z);
+                }
+            }
+            block_bbox(lo0, lo1, lo2, hi0, hi1, hi2);
+            if (hi0 < 0) continue;
+            const int e0 = hi0 - lo0 + 1, e1 = hi1 - lo1 + 1, e2 = hi2 - lo2 + 1;
+            const bool fits = e0 * e1 * e2 <= BOX_CAP;
+            if (fits) {
+                for (int i = tid; i < e0 * e1 * e2; i += BLOCK) box[i] = 0.0;
+                __syncthreads();
+            }
+#pragma unroll 1
+            for (int k = 0; k < BOX_NB; k++) {
+                const int j = j0 + k * STRIDE;
+                if (mine && st < cnts[j]) {
+                    const size_t row = (size_t)(r0 + j) * p.M;
+                    const float mm = msgs[row + st];
+                    const int pv = load_packed<PACKED>(vox + row * (PACKED ? 1 : 3), st);
+                    const int x = pv >> 20, y = (pv >> 10) & 1023, z = pv & 1023;
+                    if (fits)
+                        __hip_atomic_fetch_add(box + ((x - lo0) * e1 + (y - lo1)) * e2 + (z - lo2),
+                                               (double)mm, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else
+                        __hip_atomic_fetch_add(acc_out + lin_of<PACKED>(p, pv), mm,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (fits) {
+                __syncthreads();
+                flush_box(lo0, lo1, lo2, e0, e1, e2);
+            }
         }
     }
 }
@@ -1390,9 +1430,7 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
             hipLaunchKernelGGL((k_scatter_tile<PACKED>), dim3((n + WAVE - 1) / WAVE), dim3(BLOCK),
                                0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, xcd_stride);
         else if (mode == 2)
-            hipLaunchKernelGGL((k_scatter_box<PACKED>),
-                               dim3(((n + BOX_RAYS - 1) / BOX_RAYS) *
-                                    ((ctx->p.M + BOX_STEPS - 1) / BOX_STEPS)),
+            hipLaunchKernelGGL((k_scatter_box<PACKED>), dim3((n + BOX_RAYS - 1) / BOX_RAYS),
                                dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
                                xcd_stride);
         else

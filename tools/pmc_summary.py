@@ -4,7 +4,7 @@ Usage: pmc_summary.py <pmc_dir> [out.txt]"""
 import csv, glob, os, sys, collections
 
 def short(name):
-    for k in ("k_bp", "k_scatter_slab", "k_scatter_tile", "k_sweep_map", "k_depth", "k_traverse", "k_acc_combine"):
+    for k in ("k_bp", "k_scatter_box", "k_scatter_slab", "k_scatter_tile", "k_sweep_map", "k_depth", "k_traverse", "k_acc_combine"):
         if k in name:
             return k
     return None
