@@ -254,6 +254,9 @@ typedef enum {
 int rn_prof_begin(rn_ctx *ctx, int32_t capacity);
 int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *n_rays_host,
                 float *ms_host);
+/* after rn_prof_end: start of every recorded launch, in ms after the first one's start
+ * (the gaps between launches = what the host side costs; tools/timeline.py) */
+int rn_prof_offsets(rn_ctx *ctx, float *start_ms_host);
 
 /* ---- differentiable MRF block (training) --------------
  * The reference builds this block from TensorFlow ops and lets autodiff

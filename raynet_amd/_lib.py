@@ -98,6 +98,7 @@ SIGNATURES = {
     "rn_train_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _P],
     "rn_train_bp_sweep_bwd": [_P, _I] + [_P] * 11,
     "rn_train_depth_bwd": [_P, _I] + [_P] * 10,
+    "rn_prof_offsets": [_P, _P],
     "rn_timer_start": [_P, _P],
     "rn_timer_stop": [_P, _P, ctypes.POINTER(_F)],
 }

@@ -1963,6 +1963,13 @@ int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *
     return RN_OK;
 }
 
+int rn_prof_offsets(rn_ctx *ctx, float *start_ms_host) {
+    if (!ctx || !start_ms_host) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    for (int i = 0; i < ctx->prof_n; i++)
+        RN_HIP(ctx, hipEventElapsedTime(start_ms_host + i, ctx->prof_ev[0], ctx->prof_ev[2 * i]));
+    return RN_OK;
+}
+
 #ifdef RN_SCATTER_STATS
 int rn_debug_scatter_stats(unsigned long long *out_host, int reset) {
     if (out_host &&

@@ -236,6 +236,30 @@ class MultiViewCNNVoxelSpaceForwardPass(ForwardPass):
             yield depth_map.cpu().numpy().reshape(W, H).T
 
 
+class _Messages(dict):
+    """Per-image message rows of the resident path.  The kernels neither read nor write a
+    row beyond its ray's voxel count, so the buffers are not zero-filled per pass (2.4 GB of
+    memset at config-2 size); whoever LOOKS at an image's messages gets the reference's
+    zero-initialised view -- the tail (and the rows of rays that send nothing, count <= 1)
+    is cleared on first access."""
+
+    def __init__(self):
+        super(_Messages, self).__init__()
+        self._tail = {}
+
+    def put(self, r, msgs, counts):
+        dict.__setitem__(self, r, msgs)
+        self._tail[r] = counts
+
+    def __getitem__(self, r):
+        m = dict.__getitem__(self, r)
+        counts = self._tail.pop(r, None)
+        if counts is not None and m.numel():
+            live = torch.where(counts > 1, counts, torch.zeros_like(counts))
+            m.masked_fill_(torch.arange(m.shape[1], device=m.device)[None, :] >= live[:, None], 0.0)
+        return m
+
+
 class RayNetForwardPass(ForwardPass):
     """forward_pass.py:488-748."""
 
@@ -260,13 +284,16 @@ class RayNetForwardPass(ForwardPass):
         tile = os.environ.get("RAYNET_RAY_TILE", "16x16")
         self.ray_tile = tuple(int(t) for t in tile.split("x")) if "x" in tile else None
         self._ray_lists = {}
+        self._cam_cache = None
+        self._table_cache = None
+        self._side_stream = None
         self.ref_idx = -1
         self._ctx = None
         self._de = None
         self.timings = {}
         # state kept for inspection by tests / tools
         self.accumulator = None
-        self.messages = {}       # per image: [rows, M] messages of this rank's rays
+        self.messages = _Messages()   # per image: [rows, M] messages of this rank's rays
         self.voxel_count = {}
         self.ray_index = {}      # per image: ray index (pixel x*H + y) of every row
 
@@ -356,7 +383,10 @@ class RayNetForwardPass(ForwardPass):
             cam_host[k, :12 * N] = P.ravel()
             cam_host[k, 12 * N:12 * N + 12] = P_inv.ravel()
             cam_host[k, 12 * N + 12:] = center
-        cam_dev = ctx.dev(cam_host)
+        key = cam_host.tobytes()
+        if self._cam_cache is None or self._cam_cache[0] != key:
+            self._cam_cache = (key, ctx.dev(cam_host))
+        cam_dev = self._cam_cache[1]
 
         # K1 prefix once per reference image; the per-ray columns of ALL images live in one
         # scene-wide buffer each (image k owns rows [k*npad, k*npad + n)), so that every BP
@@ -389,7 +419,7 @@ class RayNetForwardPass(ForwardPass):
         npad = (npad + 255) // 256 * 256            # scatter tiles never straddle two images
         vox_all = torch.empty((V * npad, M), dtype=torch.int32, device=dev)
         Sr_all = torch.empty((V * npad, M), dtype=torch.float32, device=dev)
-        msgs_all = torch.zeros((V * npad, M), dtype=torch.float32, device=dev)
+        msgs_all = torch.empty((V * npad, M), dtype=torch.float32, device=dev)   # see _Messages
         rvc_all = torch.zeros((V * npad,), dtype=torch.int32, device=dev)   # padding rays: count 0
         per_image = {}
         orders = {}
@@ -421,8 +451,10 @@ class RayNetForwardPass(ForwardPass):
             # every image traverses / sweeps the same ray list: two launches for the scene
             ridx, lo, hi, total = shards[0]
             order = order_for(ridx, lo, hi, [scene.get_image(v) for v in views_of[refs[0]]])
-            table = torch.tensor([[bank[v].data_ptr() for v in views_of[r]] for r in refs],
-                                 dtype=torch.int64).to(dev)
+            ptrs = tuple(tuple(bank[v].data_ptr() for v in views_of[r]) for r in refs)
+            if self._table_cache is None or self._table_cache[0] != ptrs:
+                self._table_cache = (ptrs, torch.tensor(ptrs, dtype=torch.int64).to(dev))
+            table = self._table_cache[1]
             ctx.scene_prepare_all(V, npad, ridx, table, cam_dev, vox_all, rvc_all, Sr_all,
                                   order=order)
         else:
@@ -461,32 +493,57 @@ class RayNetForwardPass(ForwardPass):
             acc_in, acc_next = acc_next, acc_in
         self.accumulator = ctx.acc_to_grid(acc_in)
 
-        # depth sweep: one launch over the scene (each image measures from its own camera
-        # centre); maps are copied back asynchronously and handed out in order (the
-        # reference yields after each image's `.get()`)
+        # depth sweep.  One rank: image by image, and while image k+1 is decoded a side stream
+        # maps image k's rows to pixels and copies the map to (pinned) host memory -- the
+        # reference yields after each image's `.get()`.  Several ranks: one launch over the
+        # scene (each image measures from its own camera centre) and one all-reduce.
+        identity = not patch_rows and not self._filter_out_rays
+        cuda = dev.type == "cuda"
+
+        def to_host(src, r):
+            if not identity:
+                # rows -> pixels on the device (rays that were filtered out stay 0)
+                full = torch.zeros((H * W,), dtype=torch.float32, device=dev)
+                full.index_copy_(0, lists[r].long(), src)
+                src = full
+            host = torch.empty((H * W,), dtype=torch.float32, pin_memory=cuda)
+            host.copy_(src, non_blocking=True)
+            done = torch.cuda.Event() if cuda else None
+            if done is not None:
+                done.record()
+            return host, done
+
         depth_all = torch.zeros((n_all,), dtype=torch.float32, device=dev)
-        if self.reference_quirks and refs:
-            # the loop variable leaks -- every image is decoded with the LAST
-            # image's messages
-            last = per_image[refs[-1]]
+        pending = []
+        if world == 1:
+            if cuda and self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream if cuda else None
+            if side is not None:
+                depth_all.record_stream(side)
+            last = per_image[refs[-1]] if refs else None
             for r in refs:
                 st = per_image[r]
-                msgs = last["msgs"] if last["n"] == st["n"] else st["msgs"]
-                ctx.scene_depth(st["Sr"], st["vox"], st["rvc"], acc_in, msgs, st["center"], None,
-                                depth_all[st["row0"]:st["row0"] + st["n"]])
-        elif B_all == n_all:
+                msgs = st["msgs"]
+                if self.reference_quirks and last["n"] == st["n"]:
+                    msgs = last["msgs"]   # every image decoded with the LAST one's
+                dst = depth_all[st["row0"]:st["row0"] + st["n"]]
+                B = B_all if B_all < n_all else max(st["n"], 1)
+                for i in range(0, st["n"], B):
+                    ctx.scene_depth(st["Sr"][i:i + B], st["vox"][i:i + B], st["rvc"][i:i + B],
+                                    acc_in, msgs[i:i + B], st["center"], None, dst[i:i + B])
+                if side is None:
+                    pending.append((r,) + to_host(dst, r))
+                else:
+                    ready = torch.cuda.Event()
+                    ready.record()
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        pending.append((r,) + to_host(dst, r))
+        else:
             centers = cam_dev[:, 12 * N + 12:].contiguous()
             ctx.scene_depth(Sr_all, vox_all, rvc_all, acc_in, msgs_all, centers, None, depth_all,
                             rays_per_center=npad)
-        else:
-            for r in refs:
-                st = per_image[r]
-                for i in range(0, st["n"], B_all):
-                    ctx.scene_depth(st["Sr"][i:i + B_all], st["vox"][i:i + B_all],
-                                    st["rvc"][i:i + B_all], acc_in, st["msgs"][i:i + B_all],
-                                    st["center"], None,
-                                    depth_all[st["row0"] + i:st["row0"] + min(i + B_all, st["n"])])
-        if world > 1:
             # every rank writes its slices into a zeroed scene-wide map; ONE all-reduce
             # (disjoint slices, zeros elsewhere) hands every rank the complete maps
             offs = np.concatenate([[0], np.cumsum([per_image[r]["total"] for r in refs])])
@@ -496,26 +553,11 @@ class RayNetForwardPass(ForwardPass):
                 merged[int(offs[k]) + st["lo"]:int(offs[k]) + st["hi"]] = \
                     depth_all[st["row0"]:st["row0"] + st["n"]]
             dist.all_reduce(merged, op=dist.ReduceOp.SUM)
-        pending = []
-        identity = not patch_rows and not self._filter_out_rays
-        for k, r in enumerate(refs):
+            for k, r in enumerate(refs):
+                pending.append((r,) + to_host(merged[int(offs[k]):int(offs[k + 1])], r))
+        for r in refs:
             st = per_image[r]
-            if world > 1:
-                src = merged[int(offs[k]):int(offs[k + 1])]
-            else:
-                src = depth_all[st["row0"]:st["row0"] + st["n"]]
-            if not identity:
-                # rows -> pixels on the device (rays that were filtered out stay 0)
-                full = torch.zeros((H * W,), dtype=torch.float32, device=dev)
-                full.index_copy_(0, lists[r].long(), src)
-                src = full
-            host = torch.empty((H * W,), dtype=torch.float32, pin_memory=dev.type == "cuda")
-            host.copy_(src, non_blocking=True)
-            done = torch.cuda.Event() if dev.type == "cuda" else None
-            if done is not None:
-                done.record()
-            pending.append((r, host, done))
-            self.messages[r] = st["msgs"]
+            self.messages.put(r, st["msgs"], st["rvc"])
             self.voxel_count[r] = st["rvc"]
         for r, host, done in pending:
             if done is not None:

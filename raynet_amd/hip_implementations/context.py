@@ -162,6 +162,9 @@ class HipContext(object):
         ms = (ctypes.c_float * cap)()
         n = ctypes.c_int32()
         self._check(self.lib.rn_prof_end(self._h, ctypes.byref(n), ids, rays, ms))
+        starts = (ctypes.c_float * cap)()
+        self._check(self.lib.rn_prof_offsets(self._h, starts))
+        self.prof_starts = [float(starts[i]) for i in range(n.value)]
         return [(self.KERNEL_NAMES.get(ids[i], str(ids[i])), int(rays[i]), float(ms[i]))
                 for i in range(n.value)]
 
