@@ -55,10 +55,10 @@ def algorithmic_bytes(kernel, n_rays, voxels, cfg, images=1):
     per-ray voxel counts of the rays in the launch; images = reference images it covers."""
     N, F = cfg["views"], cfg["F"]
     Hf, Wf = cfg["H"] + cfg["padding"] + 1, cfg["W"] + cfg["padding"] + 1
-    if kernel == "traverse":      # write packed voxel list + count, read ray index
-        return 4 * voxels + 8 * n_rays
-    if kernel == "sweep_map":     # N feature maps once; read voxel list, write column
-        return images * 4 * N * F * Hf * Wf + 8 * voxels + 8 * n_rays
+    if kernel == "traverse":      # write packed voxel list + count + ray segment, read ray index
+        return 4 * voxels + 40 * n_rays
+    if kernel == "sweep_map":     # N feature maps once; read voxel list + segment, write column
+        return images * 4 * N * F * Hf * Wf + 8 * voxels + 40 * n_rays
     if kernel == "bp":            # Sr, voxel list, msg in, acc gather, msg out
         return 20 * voxels + 4 * n_rays
     if kernel == "scatter":       # msg, voxel list, atomic RMW of the accumulator (8)
@@ -230,7 +230,8 @@ def main():
 
     if rank == 0:
         result = {
-            "metric": "rays/sec (whole node) at 5 views x 64 depths x 128^3 voxels",
+            "metric": "rays/sec (whole node) at %d views x %d depths x %d^3 voxels" % (
+                gp.neighbors + 1, cfg["D"], cfg["grid"][0]),
             "value": round(value, 1),
             "unit": "rays/s",
             "n_gpus": world,

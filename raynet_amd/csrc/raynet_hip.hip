@@ -428,26 +428,13 @@ __device__ __forceinline__ float gather_acc(const float *__restrict__ acc, int l
     return acc[lin];
 }
 
-// A wavefront walks through RPW consecutive rays.  The counts of all of them are fetched
-// first; while ray j is being computed the rows of ray j+1 are already in flight, so a ray
-// costs one dependent memory round trip (its accumulator gather) instead of three (count ->
-// rows -> gather): measured, the kernel is bound by that chain at 8 waves / SIMD, not by
-// instruction issue.
-#ifndef RN_RPW
-#define RN_RPW 1
-#endif
-constexpr int RPW = RN_RPW;
-inline int ray_group_blocks(int n) {
-    return (n + WAVES_PER_BLOCK * RPW - 1) / (WAVES_PER_BLOCK * RPW);
-}
-// first ray of this wavefront's group (uniform), or -1
-__device__ __forceinline__ int ray_group_of_wave(int n, int &lane) {
-    lane = threadIdx.x & (WAVE - 1);
-    const int b = xcd_block(blockIdx.x, gridDim.x);
-    const int r = (b * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * RPW;
-    return r < n ? uniform(r) : -1;
-}
-
+// One wavefront per ray.  The kernels are instantiated for the launch's M (NCH = chunks of 64
+// voxels) but a ray runs the body specialised for ITS chunk count (a uniform branch): the
+// mean ray of config 2 has 137 voxels of M = 384, and every chunk a body is compiled for
+// costs instructions whether or not the ray reaches it -- measured, k_bp sits at its
+// VALU-issue floor (SQ_INSTS_VALU x 4 cycles), so instructions are what there is to save.
+// (Also measured and dropped: walking several rays per wavefront with the next ray's rows in
+// flight -- no gain, the limit was never the dependent round trips.)
 template <int NCH>
 struct RayRows {
     float sv[NCH], mv[NCH];
@@ -476,22 +463,115 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
 // clip to [1e-5, 1-1e-5] and renormalise over the count (mrf_bp.cu:103-111)
 template <int NCH, bool CLIP_IN>
 __device__ __forceinline__ void clip_renorm_rows(float (&sv)[NCH], int count, int lane) {
+    if (!CLIP_IN) return;          // resident columns are stored clipped + renormalised
     float ssum = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         const int i = ch * WAVE + lane;
         float v = 0.0f;
-        if (i < count) {
-            v = sv[ch];
-            if (CLIP_IN) v = clampf(v, (float)1e-5, (float)(1 - 1e-5));
-        }
+        if (i < count) v = clampf(sv[ch], (float)1e-5, (float)(1 - 1e-5));
         sv[ch] = v;
         ssum += v;
     }
-    if (CLIP_IN) {
-        ssum = wave_sum(ssum);
+    ssum = wave_sum(ssum);
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) sv[ch] = sv[ch] / ssum;
+    for (int ch = 0; ch < NCH; ch++) sv[ch] = sv[ch] / ssum;
+}
+// uniform dispatch on the ray's chunk count: BODY(NB) for the smallest compiled NB >= nch
+#define RN_DISPATCH_CHUNKS(NCH, nch, BODY)                  \
+    do {                                                    \
+        if (NCH >= 1 && nch <= 1) { BODY(1); }              \
+        else if (NCH >= 2 && nch <= 2) { BODY(2); }         \
+        else if (NCH >= 3 && nch <= 3) { BODY(3); }         \
+        else if (NCH >= 4 && nch <= 4) { BODY(4); }         \
+        else if (NCH >= 6 && nch <= 6) { BODY(6); }         \
+        else if (NCH >= 8 && nch <= 8) { BODY(8); }         \
+        else if (NCH >= 12 && nch <= 12) { BODY(12); }      \
+        else { BODY(NCH); }                                 \
+    } while (0)
+
+// one BP sweep of one ray with NB >= ceil(count / 64) chunks (mrf_bp.cu:88-177)
+template <int NB, bool PACKED, bool CLIP_IN, bool SCATTER>
+__device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int lane,
+                                       const float *__restrict__ S,
+                                       const int32_t *__restrict__ vox,
+                                       const float *__restrict__ acc_in, const float *msgs_in,
+                                       float *acc_out, float *msgs_out) {
+    RayRows<NB> cur;
+    load_rows<NB, PACKED>(p, cur, S, vox, msgs_in, r, count, lane);
+    // accumulator gather (depends on the voxel rows)
+    float av[NB];
+    int lin[NB];
+#pragma unroll
+    for (int ch = 0; ch < NB; ch++) {
+        const int i = ch * WAVE + lane;
+        av[ch] = 0.0f;
+        lin[ch] = 0;
+        if (ch * WAVE < count && i < count) {
+            lin[ch] = lin_of<PACKED>(p, cur.pk[ch]);
+            av[ch] = gather_acc(acc_in, lin[ch]);
+        }
+    }
+    float *mout_row = msgs_out + (size_t)r * p.M;
+    clip_renorm_rows<NB, CLIP_IN>(cur.sv, count, lane);
+
+    // pass A: occupancy, exclusive cumprod T, w = o*T*s, exclusive cumsum C
+    float ov[NB], tsv[NB], cex[NB], wv[NB];
+    float carryT = 1.0f, carryC = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NB; ch++) {
+        ov[ch] = 0.0f; tsv[ch] = 0.0f; cex[ch] = 0.0f; wv[ch] = 0.0f;
+        if (ch * WAVE < count) {
+            const int i = ch * WAVE + lane;
+            const bool valid = i < count;
+            const float o = valid ? occupancy_to_ray(av[ch], cur.mv[ch]) : 0.0f;
+            const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
+            const float T = carryT * wave_shift1(incl, 1.0f);
+            carryT = carryT * lane63(incl);
+            const float ts = T * cur.sv[ch];
+            const float w = valid ? o * ts : 0.0f;
+            const float inclC = wave_scan_add(w);
+            cex[ch] = carryC + wave_shift1(inclC, 0.0f);
+            carryC = carryC + lane63(inclC);
+            ov[ch] = o;
+            tsv[ch] = ts;
+            wv[ch] = w;
+        }
+    }
+    // (cumsum1 - cumsum2) of mrf_bp.cu:157 is the suffix sum  sum_{j>i} w_j.  The reference
+    // forms it as a difference of two running sums, which is exact-or-zero only because both
+    // are the SAME sequential sum; with wave scans that difference could go negative by an
+    // ulp (log of a negative number -> NaN), so the suffix is scanned directly.  It is
+    // non-negative by construction and free of the reference's cancellation.
+    float suf[NB];
+    {
+        float carryS = 0.0f;
+#pragma unroll
+        for (int ch = NB - 1; ch >= 0; ch--) {
+            suf[ch] = 0.0f;
+            if (ch * WAVE < count) {
+                float tot;
+                suf[ch] = carryS + wave_suffix_excl(wv[ch], lane, tot);
+                carryS = carryS + tot;
+            }
+        }
+    }
+    // pass B: messages (mrf_bp.cu:136-167) and, optionally, the scatter (:170-176)
+#pragma unroll
+    for (int ch = 0; ch < NB; ch++) {
+        if (ch * WAVE < count) {
+            const int i = ch * WAVE + lane;
+            if (i < count) {
+                float pos = cex[ch] + tsv[ch];
+                const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
+                pos = bp_div(pos, pos + neg);
+                const float m = bp_log(pos) - bp_log(1.0f - pos);
+                mout_row[i] = m;
+                if (SCATTER)
+                    __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -503,108 +583,20 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
                                               const float *msgs_in, float *acc_out,
                                               float *msgs_out, int64_t xcd_stride) {
     int lane;
-    const int rbase = ray_group_of_wave(n, lane);
-    if (rbase < 0) return;
-    // counts run two rays ahead (scalar loads), rows one ray ahead
-    auto count_of = [&](int r) {
-        const int c = r < n ? min(uniform(rvc[min(r, n - 1)]), p.M) : 0;
-        return c <= 1 ? 0 : c;         // mrf_np.py:300: such rays send nothing
-    };
-    int count = count_of(rbase), count_nxt = count_of(rbase + 1);
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    const int count = min(uniform(rvc[r]), p.M);
+    if (count <= 1) return;   // mrf_np.py:300: such rays send nothing
     if (SCATTER && xcd_stride) {
         // the XCD this workgroup really runs on; copies are private per XCD
         const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
         acc_out += xcc * xcd_stride;
     }
-    RayRows<NCH> cur, nxt;
-    load_rows<NCH, PACKED>(p, cur, S, vox, msgs_in, rbase, count, lane);
-#pragma unroll 1
-    for (int j = 0; j < RPW; j++) {
-        const int r = rbase + j;
-        const int count_nn = j + 2 < RPW ? count_of(r + 2) : 0;
-        // accumulator gather of this ray (depends on its voxel rows) ...
-        float av[NCH];
-        int lin[NCH];
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            const int i = ch * WAVE + lane;
-            av[ch] = 0.0f;
-            lin[ch] = 0;
-            if (ch * WAVE < count && i < count) {
-                lin[ch] = lin_of<PACKED>(p, cur.pk[ch]);
-                av[ch] = gather_acc(acc_in, lin[ch]);
-            }
-        }
-        // ... and, behind it, the rows of the next ray
-        if (j + 1 < RPW) load_rows<NCH, PACKED>(p, nxt, S, vox, msgs_in, r + 1, count_nxt, lane);
-        if (count > 0) {
-            float *mout_row = msgs_out + (size_t)r * p.M;
-            clip_renorm_rows<NCH, CLIP_IN>(cur.sv, count, lane);
-
-            // pass A: occupancy, exclusive cumprod T, w = o*T*s, exclusive cumsum C
-            float ov[NCH], tsv[NCH], cex[NCH], wv[NCH];
-            float carryT = 1.0f, carryC = 0.0f;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ch++) {
-                ov[ch] = 0.0f; tsv[ch] = 0.0f; cex[ch] = 0.0f; wv[ch] = 0.0f;
-                if (ch * WAVE < count) {
-                    const int i = ch * WAVE + lane;
-                    const bool valid = i < count;
-                    const float o = valid ? occupancy_to_ray(av[ch], cur.mv[ch]) : 0.0f;
-                    const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
-                    const float T = carryT * wave_shift1(incl, 1.0f);
-                    carryT = carryT * lane63(incl);
-                    const float ts = T * cur.sv[ch];
-                    const float w = valid ? o * ts : 0.0f;
-                    const float inclC = wave_scan_add(w);
-                    cex[ch] = carryC + wave_shift1(inclC, 0.0f);
-                    carryC = carryC + lane63(inclC);
-                    ov[ch] = o;
-                    tsv[ch] = ts;
-                    wv[ch] = w;
-                }
-            }
-            // (cumsum1 - cumsum2) of mrf_bp.cu:157 is the suffix sum  sum_{j>i} w_j.  The
-            // reference forms it as a difference of two running sums, which is exact-or-zero
-            // only because both are the SAME sequential sum; with wave scans that difference
-            // could go negative by an ulp (log of a negative number -> NaN), so the suffix is
-            // scanned directly.  It is non-negative by construction and free of the
-            // reference's cancellation.
-            float suf[NCH];
-            {
-                float carryS = 0.0f;
-#pragma unroll
-                for (int ch = NCH - 1; ch >= 0; ch--) {
-                    suf[ch] = 0.0f;
-                    if (ch * WAVE < count) {
-                        float tot;
-                        suf[ch] = carryS + wave_suffix_excl(wv[ch], lane, tot);
-                        carryS = carryS + tot;
-                    }
-                }
-            }
-            // pass B: messages (mrf_bp.cu:136-167) and, optionally, the scatter (:170-176)
-#pragma unroll
-            for (int ch = 0; ch < NCH; ch++) {
-                if (ch * WAVE < count) {
-                    const int i = ch * WAVE + lane;
-                    if (i < count) {
-                        float pos = cex[ch] + tsv[ch];
-                        const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
-                        pos = bp_div(pos, pos + neg);
-                        const float m = bp_log(pos) - bp_log(1.0f - pos);
-                        mout_row[i] = m;
-                        if (SCATTER)
-                            __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-        }
-        cur = nxt;
-        count = count_nxt;
-        count_nxt = count_nn;
-    }
+    const int nch = (count + WAVE - 1) / WAVE;
+#define RN_BP_BODY(NB) \
+    bp_ray<NB, PACKED, CLIP_IN, SCATTER>(p, r, count, lane, S, vox, acc_in, msgs_in, acc_out, msgs_out)
+    RN_DISPATCH_CHUNKS(NCH, nch, RN_BP_BODY);
+#undef RN_BP_BODY
 }
 
 // ------------------------------------------------- accumulator scatter, transposed
@@ -906,27 +898,24 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
 // registers (BOX_NB per thread, one round trip), the box is the exact bounding box of those
 // voxels -- no assumption on the lists -- and a chunk whose box exceeds the LDS budget (rows
 // that are not patch-ordered) goes straight to the global atomics: always correct.
-#ifndef RN_BOX_STEPS
-#define RN_BOX_STEPS 32      // 128 B of every row per round trip: whole cache lines
-#endif
 #ifndef RN_BOX_CAP
 #define RN_BOX_CAP 4096
 #endif
-#ifndef RN_BOX_RAYS
-#define RN_BOX_RAYS 128      // half a 16x16 patch
-#endif
-constexpr int BOX_STEPS = RN_BOX_STEPS;
-constexpr int BOX_RAYS = RN_BOX_RAYS;
 constexpr int BOX_CAP = RN_BOX_CAP;      // voxels (doubles of LDS) per chunk
-constexpr int BOX_NB = BOX_RAYS * BOX_STEPS / BLOCK;     // pairs per thread and chunk
+// Tile shapes (rays x steps): 128 x 32 reads 128 B of every row per round trip (whole cache
+// lines) and is the default; scenes whose bundles are too wide for the LDS budget at 32
+// steps (fine grids, oblique views) switch to 256 x 16 -- the kernel counts the chunks that
+// overflowed and the launcher looks at the previous launches' count (rn_ctx::box_*).
 __device__ __forceinline__ int wave_reduce_max(int x) { return lane63i(wave_scan_max(x)); }
 __device__ __forceinline__ int wave_reduce_min(int x) { return ~wave_reduce_max(~x); }
-template <bool PACKED>
+template <bool PACKED, int BOX_RAYS, int BOX_STEPS>
 __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                                        const float *__restrict__ msgs,
                                                        const int32_t *__restrict__ vox,
                                                        const int32_t *__restrict__ rvc,
-                                                       float *acc_out, int64_t xcd_stride) {
+                                                       float *acc_out, int64_t xcd_stride,
+                                                       unsigned *overflow_stats) {
+    constexpr int BOX_NB = BOX_RAYS * BOX_STEPS / BLOCK;     // pairs per thread and chunk
     __shared__ double box[BOX_CAP];
     __shared__ int red[2][6 * WAVES_PER_BLOCK];
     __shared__ int red_cnt[WAVES_PER_BLOCK];
@@ -1054,6 +1043,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             flush_box(lo0, lo1, lo2, d0, d1, d2);
             continue;
         }
+        if (tid == 0 && overflow_stats) atomicAdd(overflow_stats + 1, 1u);
         // ---- too big for LDS (rows that are not patch-ordered, very oblique bundles): the
         // chunk again in quarters, pairs re-read (L2-hot) so that this rare path costs the
         // common one no registers; a quarter that still does not fit takes the direct atomics
@@ -1105,10 +1095,62 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             }
         }
     }
+    if (tid == 0 && overflow_stats)
+        atomicAdd(overflow_stats, (unsigned)((maxc + BOX_STEPS - 1) / BOX_STEPS));
 }
 
 // ------------------------------------------------- K4 / K2 tail: depth estimate
 // Writes the distribution (if S_new) and/or the arg-max depth (if depth_map).
+// depth distribution of one ray with NB >= ceil(count / 64) chunks (mrf_bp.cu:37-86);
+// returns the lane's best (value, index) for the arg-max
+template <int NB, bool PACKED, bool CLIP_IN>
+__device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int lane,
+                                          const float *__restrict__ S,
+                                          const int32_t *__restrict__ vox,
+                                          const float *__restrict__ acc,
+                                          const float *__restrict__ msgs, float *S_new, float &best,
+                                          int &best_i) {
+    RayRows<NB> cur;
+    load_rows<NB, PACKED>(p, cur, S, vox, msgs, r, count, lane);
+    float av[NB];
+#pragma unroll
+    for (int ch = 0; ch < NB; ch++) {
+        const int i = ch * WAVE + lane;
+        av[ch] = 0.0f;
+        if (ch * WAVE < count && i < count) av[ch] = gather_acc(acc, lin_of<PACKED>(p, cur.pk[ch]));
+    }
+    clip_renorm_rows<NB, CLIP_IN>(cur.sv, count, lane);
+    float wv[NB];
+    float carryT = 1.0f, wsum = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NB; ch++) {
+        wv[ch] = 0.0f;
+        if (ch * WAVE < count) {
+            const int i = ch * WAVE + lane;
+            const bool valid = i < count;
+            const float o = valid ? occupancy_to_ray(av[ch], cur.mv[ch]) : 0.0f;
+            const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
+            const float T = carryT * wave_shift1(incl, 1.0f);
+            carryT = carryT * lane63(incl);
+            wv[ch] = valid ? o * T * cur.sv[ch] : 0.0f;
+            wsum += wv[ch];
+        }
+    }
+    wsum = wave_sum(wsum);
+#pragma unroll
+    for (int ch = 0; ch < NB; ch++) {
+        const int i = ch * WAVE + lane;
+        if (ch * WAVE < count && i < count) {
+            const float d = bp_div(wv[ch], wsum);
+            if (S_new) S_new[(size_t)r * p.M + i] = d;
+            if (d > best) {   // ascending i per lane: keeps the first maximum
+                best = d;
+                best_i = i;
+            }
+        }
+    }
+}
+
 template <int NCH, bool PACKED, bool CLIP_IN>
 __global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S,
                                                  const int32_t *__restrict__ vox,
@@ -1116,100 +1158,49 @@ __global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S
                                                  const float *__restrict__ acc,
                                                  const float *__restrict__ msgs,
                                                  const float *__restrict__ axes,
-                                                 const float *__restrict__ cc_all, float *S_new,
+                                                 const float *__restrict__ cc, float *S_new,
                                                  float *depth_map, int rays_per_center) {
     int lane;
-    const int rbase = ray_group_of_wave(n, lane);
-    if (rbase < 0) return;
-    auto count_of = [&](int r) { return r < n ? min(uniform(rvc[min(r, n - 1)]), p.M) : 0; };
-    int count = count_of(rbase), count_nxt = count_of(rbase + 1);
-    // same pipeline as k_bp: rows of ray j+1 in flight while ray j is computed
-    RayRows<NCH> cur, nxt;
-    load_rows<NCH, PACKED>(p, cur, S, vox, msgs, rbase, count > 1 ? count : 0, lane);
-#pragma unroll 1
-    for (int j = 0; j < RPW; j++) {
-        const int r = rbase + j;
-        const int count_nn = j + 2 < RPW ? count_of(r + 2) : 0;
-        float av[NCH];
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    if (rays_per_center > 0 && cc) cc += 4 * (r / rays_per_center);
+    const int count = min(uniform(rvc[r]), p.M);
+    float best = -INFINITY;
+    int best_i = 0;
+    if (count > 1) {
+        const int nch = (count + WAVE - 1) / WAVE;
+#define RN_DE_BODY(NB) \
+    depth_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc, msgs, S_new, best, best_i)
+        RN_DISPATCH_CHUNKS(NCH, nch, RN_DE_BODY);
+#undef RN_DE_BODY
+    } else if (S_new) {
+        // mrf_np.py:370-377: skipped rays keep an all-zero row (first `count` entries)
+        for (int i = lane; i < count; i += WAVE) S_new[(size_t)r * p.M + i] = 0.0f;
+    }
+    if (!depth_map) return;
+    // raynet_fp.py:193-226.  Entries beyond count are zero in the reference's zero-filled
+    // buffer and every d_i > 0, so the arg-max lies in [0, count); for count <= 1 the row is
+    // all zeros and index 0 wins.
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            const int i = ch * WAVE + lane;
-            av[ch] = 0.0f;
-            if (count > 1 && ch * WAVE < count && i < count)
-                av[ch] = gather_acc(acc, lin_of<PACKED>(p, cur.pk[ch]));
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(best_i, o);
+        if (ob > best || (ob == best && oi < best_i)) {
+            best = ob;
+            best_i = oi;
         }
-        if (j + 1 < RPW)
-            load_rows<NCH, PACKED>(p, nxt, S, vox, msgs, r + 1, count_nxt > 1 ? count_nxt : 0, lane);
-        if (r < n) {
-            float best = -INFINITY;
-            int best_i = 0;
-            if (count > 1) {
-                clip_renorm_rows<NCH, CLIP_IN>(cur.sv, count, lane);
-                float wv[NCH];
-                float carryT = 1.0f, wsum = 0.0f;
-#pragma unroll
-                for (int ch = 0; ch < NCH; ch++) {
-                    wv[ch] = 0.0f;
-                    if (ch * WAVE < count) {
-                        const int i = ch * WAVE + lane;
-                        const bool valid = i < count;
-                        const float o = valid ? occupancy_to_ray(av[ch], cur.mv[ch]) : 0.0f;
-                        const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
-                        const float T = carryT * wave_shift1(incl, 1.0f);
-                        carryT = carryT * lane63(incl);
-                        wv[ch] = valid ? o * T * cur.sv[ch] : 0.0f;
-                        wsum += wv[ch];
-                    }
-                }
-                wsum = wave_sum(wsum);
-#pragma unroll
-                for (int ch = 0; ch < NCH; ch++) {
-                    const int i = ch * WAVE + lane;
-                    if (ch * WAVE < count && i < count) {
-                        const float d = bp_div(wv[ch], wsum);
-                        if (S_new) S_new[(size_t)r * p.M + i] = d;
-                        if (d > best) {   // ascending i per lane: keeps the first maximum
-                            best = d;
-                            best_i = i;
-                        }
-                    }
-                }
-            } else if (S_new) {
-                // mrf_np.py:370-377: skipped rays keep an all-zero row (first `count` entries)
-                for (int i = lane; i < count; i += WAVE) S_new[(size_t)r * p.M + i] = 0.0f;
-            }
-            if (depth_map) {
-                // raynet_fp.py:193-226.  Entries beyond count are zero in the reference's
-                // zero-filled buffer and every d_i > 0, so the arg-max lies in [0, count);
-                // for count <= 1 the row is all zeros and index 0 wins.
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ob = __shfl_xor(best, o);
-                    const int oi = __shfl_xor(best_i, o);
-                    if (ob > best || (ob == best && oi < best_i)) {
-                        best = ob;
-                        best_i = oi;
-                    }
-                }
-                if (lane == 0) {
-                    const float *cc =
-                        rays_per_center > 0 && cc_all ? cc_all + 4 * (r / rays_per_center) : cc_all;
-                    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
-                    int x = 0, y = 0, z = 0;
-                    if (count > 0) load_voxel<PACKED>(vrow, count > 1 ? best_i : 0, x, y, z);
-                    const float pt[3] = {axes[x], axes[p.gx + y], axes[p.gx + p.gy + z]};
-                    float sum = 0.0f;
-                    for (int i = 0; i < 3; i++) {
-                        const float d = pt[i] - cc[i];
-                        sum += d * d;
-                    }
-                    depth_map[r] = sqrtf(sum);
-                }
-            }
+    }
+    if (lane == 0) {
+        const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+        int x = 0, y = 0, z = 0;
+        if (count > 0) load_voxel<PACKED>(vrow, count > 1 ? best_i : 0, x, y, z);
+        const float pt[3] = {axes[x], axes[p.gx + y], axes[p.gx + p.gy + z]};
+        float sum = 0.0f;
+        for (int i = 0; i < 3; i++) {
+            const float d = pt[i] - cc[i];
+            sum += d * d;
         }
-        cur = nxt;
-        count = count_nxt;
-        count_nxt = count_nn;
+        depth_map[r] = sqrtf(sum);
     }
 }
 
@@ -1272,6 +1263,10 @@ struct rn_ctx {
     int acc_mode;         // 0: one accumulator copy; 1: one copy per XCD (A/B knob)
     bool fused_scatter;   // scatter from inside k_bp instead of a scatter kernel (A/B knob)
     int scatter_mode;     // A/B knob: -1 by row layout (default), 0 slab, 1 step-ordered tile, 2 LDS box
+    // LDS-box scatter: chunk length in use (32, or 16 once too many 32-step chunks overflowed),
+    // {chunks, overflowed chunks} of the previous launches on the device / pinned host mirror
+    int box_steps;
+    unsigned *box_stats, *box_stats_host;
     hipEvent_t ev0, ev1;
     // per-launch profiling (rn_prof_begin / rn_prof_end)
     bool prof_on;
@@ -1406,12 +1401,12 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
 #define RN_BP(NCH_)                                                                         \
     do {                                                                                    \
         if (fused)                                                                          \
-            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, true>), dim3(ray_group_blocks(n)), \
+            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, true>), dim3(ray_blocks(n)), \
                                dim3(BLOCK), bp_lds, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in,  \
                                acc_out, msgs_out, xcd_stride);                               \
         else                                                                                \
             hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, false>),                   \
-                               dim3(ray_group_blocks(n)), dim3(BLOCK), bp_lds, st, ctx->p, n, Sv,   \
+                               dim3(ray_blocks(n)), dim3(BLOCK), bp_lds, st, ctx->p, n, Sv,   \
                                vox, rvc, acc_in, msgs_in, acc_out, msgs_out, xcd_stride);    \
     } while (0)
         if (nch <= 2) RN_BP(2);
@@ -1430,9 +1425,26 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
             hipLaunchKernelGGL((k_scatter_tile<PACKED>), dim3((n + WAVE - 1) / WAVE), dim3(BLOCK),
                                0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, xcd_stride);
         else if (mode == 2)
-            hipLaunchKernelGGL((k_scatter_box<PACKED>), dim3((n + BOX_RAYS - 1) / BOX_RAYS),
-                               dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
-                               xcd_stride);
+        {
+            // previous launches' overflow count (copied out asynchronously, may lag a launch):
+            // more than 2 % of the chunks did not fit -> narrower chunks from now on
+            if (ctx->box_steps == 32 && ctx->box_stats_host[0] > 0 &&
+                ctx->box_stats_host[1] * 50u > ctx->box_stats_host[0])
+                ctx->box_steps = 16;
+            if (ctx->box_steps == 32)
+                hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32>), dim3((n + 127) / 128),
+                                   dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
+                                   xcd_stride, ctx->box_stats);
+            else
+                hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16>), dim3((n + 255) / 256),
+                                   dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
+                                   xcd_stride, (unsigned *)nullptr);
+            if (ctx->box_steps == 32) {
+                (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
+                                     hipMemcpyDeviceToHost, st);
+                (void)hipMemsetAsync(ctx->box_stats, 0, 2 * sizeof(unsigned), st);
+            }
+        }
         else
             hipLaunchKernelGGL((k_scatter_slab<PACKED>),
                                dim3(((n + WAVE - 1) / WAVE) *
@@ -1451,7 +1463,7 @@ int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const 
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     ProfScope prof(ctx, RN_K_DEPTH, n, st);
 #define RN_DE(NCH_)                                                                             \
-    hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_group_blocks(n)), dim3(BLOCK), 0, st, \
+    hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
                        ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, S_new, depth_map,           \
                        rays_per_center)
     if (nch <= 2) RN_DE(2);
@@ -1499,6 +1511,9 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     if ((int64_t)((cfg->grid[0] + 3) / 4) * ((cfg->grid[1] + 3) / 4) * ((cfg->grid[2] + 3) / 4) >=
         ((int64_t)1 << 24))
         return RN_ERR_INVALID;        // accumulator indices are 32-bit
+    if ((int64_t)(cfg->H + cfg->padding + 1) * (cfg->W + cfg->padding + 1) * cfg->F >=
+        ((int64_t)1 << 29))
+        return RN_ERR_INVALID;        // feature vectors are addressed with 32-bit byte offsets
     if (hipSetDevice(cfg->device) != hipSuccess) return RN_ERR_HIP;
     rn_ctx *ctx = new rn_ctx();
     memset(ctx, 0, sizeof(*ctx));
@@ -1519,11 +1534,17 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     const char *sm = getenv("RAYNET_HIP_SCATTER_MODE");
     ctx->scatter_mode = sm ? atoi(sm) : -1;
     ctx->copies = ctx->acc_mode == 0 ? 1 : NXCD;
+    const char *bs = getenv("RAYNET_HIP_BOX_STEPS");      // A/B knob: pin the chunk length
+    ctx->box_steps = bs && atoi(bs) == 16 ? 16 : 32;
     if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
+        hipMalloc(&ctx->box_stats, 2 * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc(&ctx->box_stats_host, 2 * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(ctx->box_stats, 0, 2 * sizeof(unsigned)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return RN_ERR_HIP;
     }
+    ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
     if (sweep_lds(p) > 160 * 1024) {
         hipFree(ctx->axes);
         delete ctx;
@@ -1537,6 +1558,8 @@ void rn_destroy(rn_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->cfg.device);
     if (ctx->axes) hipFree(ctx->axes);
+    if (ctx->box_stats) hipFree(ctx->box_stats);
+    if (ctx->box_stats_host) hipHostFree(ctx->box_stats_host);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 2 * ctx->prof_cap; i++) hipEventDestroy(ctx->prof_ev[i]);

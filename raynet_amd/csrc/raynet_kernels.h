@@ -21,6 +21,9 @@ namespace rn {
 constexpr int WAVE = 64;
 constexpr int MAX_VIEWS = 16;
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
 struct Params {
     int M, D, N, F, H, W, padding;
     int gx, gy, gz;
@@ -223,26 +226,31 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
     const int pairs = (NV * (NV - 1)) / 2;
     for (int base = 0; base < p.D; base += WAVE) {
         // lane k projects plane base+k into every view
-        int off[NV];
+        int offb[NV];           // BYTE offset of the plane's feature vector in every view
         {
             const int k = min(base + lane, p.D - 1);
             float point[3];
             plane_point(s, e, k, p.D, point);
 #pragma unroll
-            for (int v = 0; v < NV; v++) off[v] = feature_offset(p, P + 12 * v, point);
+            for (int v = 0; v < NV; v++) offb[v] = feature_offset(p, P + 12 * v, point) * 4;
         }
         float mine = 0.0f;
 #pragma unroll 2
         for (int it = 0; it < LPS; it++) {
             const int src = it * SPL + sub;   // plane (within the chunk) this lane helps with
-            float4 f[NV];
+            // lane's 16 bytes of every view's vector, as two channel pairs: the packed FMAs
+            // below then work on the register pairs exactly as the loads deliver them
+            float2v flo[NV], fhi[NV];
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                // unsigned element offset from a uniform base: one load with a 32-bit
-                // register offset, no 64-bit address arithmetic per lane
-                const unsigned ob = ((unsigned)__shfl(off[v], src) + 4u * (unsigned)part) * 4u;
-                f[v] = *reinterpret_cast<const float4 *>(
-                    reinterpret_cast<const char *>(vbase[v]) + (size_t)ob);
+                // byte offset from a uniform GLOBAL base: one load with a 32-bit register
+                // offset (global_load ... s[base]), no 64-bit address arithmetic per lane
+                const unsigned ob = (unsigned)__shfl(offb[v], src) + 16u * (unsigned)part;
+                typedef const __attribute__((address_space(1))) char *gptr;
+                typedef const __attribute__((address_space(1))) float4v *gptr4;
+                const float4v f = *(gptr4)((gptr)vbase[v] + ob);
+                flo[v] = float2v{f.x, f.y};
+                fhi[v] = float2v{f.z, f.w};
             }
             // sum over view pairs i<j of <f_i, f_j>, as  sum_j <f_0 + ... + f_{j-1}, f_j>  on this
             // lane's 4 channels: NV-1 packed FMAs and NV-2 packed adds per channel pair instead
@@ -252,19 +260,19 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             float acc;
             {
 #pragma clang fp contract(fast)
-                float4 run = f[0];
-                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float2v rlo = flo[0], rhi = fhi[0];
+                float2v alo = float2v{0.f, 0.f}, ahi = float2v{0.f, 0.f};
 #pragma unroll
                 for (int j = 1; j < NV; j++) {
-                    a4.x = run.x * f[j].x + a4.x;
-                    a4.y = run.y * f[j].y + a4.y;
-                    a4.z = run.z * f[j].z + a4.z;
-                    a4.w = run.w * f[j].w + a4.w;
+                    alo = rlo * flo[j] + alo;
+                    ahi = rhi * fhi[j] + ahi;
                     if (j + 1 < NV) {
-                        run.x += f[j].x; run.y += f[j].y; run.z += f[j].z; run.w += f[j].w;
+                        rlo += flo[j];
+                        rhi += fhi[j];
                     }
                 }
-                acc = (a4.x + a4.y) + (a4.z + a4.w);
+                const float2v t = alo + ahi;
+                acc = t.x + t.y;
             }
 #pragma unroll
             for (int m = 1; m < LPS; m <<= 1) acc += __shfl_xor(acc, m);
