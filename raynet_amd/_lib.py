@@ -115,6 +115,10 @@ def load():
         raise RaynetHipError(
             "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(raynet_amd has no CPU fallback)" % LIB_PATH)
+    # torch first: it brings its own libamdhip64, and a process must not end up with two HIP
+    # runtimes (the library loaded before torch would bind /opt/rocm's copy and then see no
+    # device once torch has initialised the other one)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
