@@ -205,8 +205,9 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
  * inside a brick for ~4 steps, so a wavefront's gather touches ~4x fewer cache lines than in
  * the [gx][gy][gz] array).  rn_acc_to_grid / rn_acc_from_grid convert to / from the
  * reference's [gx][gy][gz] layout (mrf_bp.cu:3-10); padding voxels are never read back.
- * acc_part: [rn_acc_copies()][rn_acc_size()] f32, zero before the first sweep of an
- * iteration; messages are scattered into one copy per XCD. */
+ * acc_part: [rn_acc_copies()][rn_acc_size()] f32 partial accumulator(s) the sweep scatters
+ * into, zero before the first sweep of an iteration (rn_acc_copies() is 1: per-XCD copies
+ * were measured and bought nothing). */
 int64_t rn_acc_size(const rn_ctx *ctx);
 int rn_acc_to_grid(rn_ctx *ctx, const float *acc, float *grid_out, void *stream);
 int rn_acc_from_grid(rn_ctx *ctx, const float *grid, float *acc_out, void *stream);

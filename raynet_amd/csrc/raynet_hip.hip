@@ -394,14 +394,13 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
 }
 
 // ------------------------------------------------------------- K3: BP sweep
-// One wavefront per ray, NCH chunks of 64 voxels held in registers.
-//   CLIP_IN: S is the raw voxel-space column (API mode) and is clipped +
-//            renormalised here; otherwise it is the resident Sr.
-//   SCATTER: add the messages to acc_out with one atomic per voxel from this kernel
-//            (lanes = consecutive voxels of ONE ray: 64 different cache lines per
-//            instruction).  The drivers use SCATTER=false + k_scatter_slab instead.
+// One wavefront per ray, chunks of 64 voxels held in registers.
+//   CLIP_IN: S is the raw voxel-space column (API mode) and is clipped + renormalised here;
+//            otherwise it is the resident Sr.
 //   msgs_in == nullptr means "all messages are zero" (first sweep): nothing is read.
-// The kernel is latency bound (about three dependent memory round trips per ray), so the
+// The messages go to msgs_out; adding them to the accumulator is the scatter kernels' job
+// (from inside this kernel the lanes are consecutive voxels of ONE ray: 64 different cache
+// lines per atomic instruction, 5x slower in total).
 template <bool PACKED>
 __device__ __forceinline__ int load_packed(const int32_t *__restrict__ row, int i) {
     if (PACKED) return row[i];
@@ -491,26 +490,21 @@ __device__ __forceinline__ void clip_renorm_rows(float (&sv)[NCH], int count, in
     } while (0)
 
 // one BP sweep of one ray with NB >= ceil(count / 64) chunks (mrf_bp.cu:88-177)
-template <int NB, bool PACKED, bool CLIP_IN, bool SCATTER>
+template <int NB, bool PACKED, bool CLIP_IN>
 __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int lane,
                                        const float *__restrict__ S,
                                        const int32_t *__restrict__ vox,
                                        const float *__restrict__ acc_in, const float *msgs_in,
-                                       float *acc_out, float *msgs_out) {
+                                       float *msgs_out) {
     RayRows<NB> cur;
     load_rows<NB, PACKED>(p, cur, S, vox, msgs_in, r, count, lane);
     // accumulator gather (depends on the voxel rows)
     float av[NB];
-    int lin[NB];
 #pragma unroll
     for (int ch = 0; ch < NB; ch++) {
         const int i = ch * WAVE + lane;
         av[ch] = 0.0f;
-        lin[ch] = 0;
-        if (ch * WAVE < count && i < count) {
-            lin[ch] = lin_of<PACKED>(p, cur.pk[ch]);
-            av[ch] = gather_acc(acc_in, lin[ch]);
-        }
+        if (ch * WAVE < count && i < count) av[ch] = gather_acc(acc_in, lin_of<PACKED>(p, cur.pk[ch]));
     }
     float *mout_row = msgs_out + (size_t)r * p.M;
     clip_renorm_rows<NB, CLIP_IN>(cur.sv, count, lane);
@@ -556,7 +550,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
             }
         }
     }
-    // pass B: messages (mrf_bp.cu:136-167) and, optionally, the scatter (:170-176)
+    // pass B: messages (mrf_bp.cu:136-167); the scatter (:170-176) is a kernel of its own
 #pragma unroll
     for (int ch = 0; ch < NB; ch++) {
         if (ch * WAVE < count) {
@@ -567,113 +561,32 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
                 pos = bp_div(pos, pos + neg);
                 const float m = bp_log(pos) - bp_log(1.0f - pos);
                 mout_row[i] = m;
-                if (SCATTER)
-                    __hip_atomic_fetch_add(acc_out + lin[ch], m, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
 }
 
-template <int NCH, bool PACKED, bool CLIP_IN, bool SCATTER>
+template <int NCH, bool PACKED, bool CLIP_IN>
 __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
                                               const int32_t *__restrict__ vox,
                                               const int32_t *__restrict__ rvc,
                                               const float *__restrict__ acc_in,
-                                              const float *msgs_in, float *acc_out,
-                                              float *msgs_out, int64_t xcd_stride) {
+                                              const float *msgs_in, float *msgs_out) {
     int lane;
     const int r = ray_of_wave(n, lane);
     if (r < 0) return;
     const int count = min(uniform(rvc[r]), p.M);
     if (count <= 1) return;   // mrf_np.py:300: such rays send nothing
-    if (SCATTER && xcd_stride) {
-        // the XCD this workgroup really runs on; copies are private per XCD
-        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
-        acc_out += xcc * xcd_stride;
-    }
     const int nch = (count + WAVE - 1) / WAVE;
 #define RN_BP_BODY(NB) \
-    bp_ray<NB, PACKED, CLIP_IN, SCATTER>(p, r, count, lane, S, vox, acc_in, msgs_in, acc_out, msgs_out)
+    bp_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc_in, msgs_in, msgs_out)
     RN_DISPATCH_CHUNKS(NCH, nch, RN_BP_BODY);
 #undef RN_BP_BODY
 }
 
-// ------------------------------------------------- accumulator scatter, transposed
-// mrf_bp.cu:170-176 (acc_out[voxel] += message) for a tile of 64 CONSECUTIVE rays.
-// A float atomic costs one L2 request per distinct cache line of the instruction
-// (measured: 21 G scattered vs 324 G coalesced atomics/s, tools/atomic_bench.hip).  With
-// lanes = voxels of one ray every lane hits its own line.  Here the [64 rays][64 steps]
-// message / voxel tiles go through LDS and are read back transposed, so one instruction
-// carries step s of 64 neighbouring rays: neighbouring pixels of an image column pierce
-// the same or vertically adjacent voxels, i.e. consecutive floats of the z-fastest grid.
-constexpr int TILE_PAD = 65;
-template <bool PACKED>
-__global__ __launch_bounds__(BLOCK) void k_scatter_tile(Params p, int n,
-                                                        const float *__restrict__ msgs,
-                                                        const int32_t *__restrict__ vox,
-                                                        const int32_t *__restrict__ rvc,
-                                                        float *acc_out, int64_t xcd_stride) {
-    __shared__ float tile_m[WAVE * TILE_PAD];
-    __shared__ int32_t tile_v[WAVE * TILE_PAD];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wid = threadIdx.x >> 6;
-    const int r0 = xcd_block(blockIdx.x, gridDim.x) * WAVE;
-    if (xcd_stride) {
-        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
-        acc_out += xcc * xcd_stride;
-    }
-    // lane = ray of the tile
-    int cnt = 0;
-    if (r0 + lane < n) {
-        cnt = min(rvc[r0 + lane], p.M);
-        if (cnt <= 1) cnt = 0;        // such rays send no message (mrf_np.py:300)
-    }
-    int maxc = cnt;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
-    maxc = uniform(maxc);
-    constexpr int ROWS = WAVE / WAVES_PER_BLOCK;      // rows (and steps) per wave: 16
-    for (int base = 0; base < maxc; base += WAVE) {
-        // coalesced row loads: wave `wid` brings in rays wid*16 .. wid*16+15
-#pragma unroll 4
-        for (int j = 0; j < ROWS; j++) {
-            const int row = wid * ROWS + j;
-            const int c = __shfl(cnt, row);
-            float m = 0.0f;
-            int32_t v = 0;
-            if (base + lane < c) {
-                const size_t off = (size_t)(r0 + row) * p.M + base + lane;
-                m = msgs[off];
-                if (PACKED) {
-                    v = vox[off];
-                } else {
-                    const int32_t *t = vox + off * 3;
-                    v = pack_voxel(t[0], t[1], t[2]);
-                }
-            }
-            tile_m[row * TILE_PAD + lane] = m;
-            tile_v[row * TILE_PAD + lane] = v;
-        }
-        __syncthreads();
-        // transposed: this wave scatters steps wid*16 .. wid*16+15 of all 64 rays
-#pragma unroll 4
-        for (int j = 0; j < ROWS; j++) {
-            const int s = wid * ROWS + j;
-            if (base + s < cnt) {
-                const float m = tile_m[lane * TILE_PAD + s];
-                const int32_t v = tile_v[lane * TILE_PAD + s];
-                const int lin = lin_of<PACKED>(p, v);
-                __hip_atomic_fetch_add(acc_out + lin, m, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------- accumulator scatter, slab-ordered
-// Same job as k_scatter_tile, but the atomics of a 64-ray tile are issued in order of
+// mrf_bp.cu:170-176 (acc_out[voxel] += message) for rows in ray-index order: the atomics of
+// a tile of 64 CONSECUTIVE rays go through LDS and are issued in order of
 // the voxels' coordinate along the tile's dominant travel axis instead of in step order.
 // The 64 rays of a tile are neighbouring pixels of one image column: they lie in one
 // plane through the camera, so inside one slab of the dominant axis their voxels share
@@ -695,7 +608,7 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
                                                        const float *__restrict__ msgs,
                                                        const int32_t *__restrict__ vox,
                                                        const int32_t *__restrict__ rvc,
-                                                       float *acc_out, int64_t xcd_stride) {
+                                                       float *acc_out) {
     __shared__ float tile_m[WAVE * SLAB_PAD];
     __shared__ int32_t tile_v[WAVE * SLAB_PAD];
     const int lane = threadIdx.x;
@@ -705,10 +618,6 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
     const int lb = xcd_block(blockIdx.x, gridDim.x);
     const int r0 = (lb / nchunks) * WAVE;
     const int base = (lb % nchunks) * SLAB_STEPS;
-    if (xcd_stride) {
-        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
-        acc_out += xcc * xcd_stride;
-    }
     int cnt = 0;
     if (r0 + lane < n) {
         cnt = min(rvc[r0 + lane], p.M);
@@ -913,7 +822,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                                        const float *__restrict__ msgs,
                                                        const int32_t *__restrict__ vox,
                                                        const int32_t *__restrict__ rvc,
-                                                       float *acc_out, int64_t xcd_stride,
+                                                       float *acc_out,
                                                        unsigned *overflow_stats) {
     constexpr int BOX_NB = BOX_RAYS * BOX_STEPS / BLOCK;     // pairs per thread and chunk
     __shared__ double box[BOX_CAP];
@@ -922,10 +831,6 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
     __shared__ int cnts[BOX_RAYS];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
     const int r0 = xcd_block(blockIdx.x, gridDim.x) * BOX_RAYS;
-    if (xcd_stride) {
-        const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;
-        acc_out += xcc * xcd_stride;
-    }
     // a wavefront instruction covers RPI rays x BOX_STEPS steps; thread (sub, col) of wave w
     // owns step col of the rays w*RPI + sub + k*STRIDE
     constexpr int RPI = WAVE / BOX_STEPS;
@@ -1259,10 +1164,7 @@ struct rn_ctx {
     Params p;
     float *axes;          // device, gx+gy+gz
     bool have_axes;
-    int copies;           // accumulator copies used by the resident path
-    int acc_mode;         // 0: one accumulator copy; 1: one copy per XCD (A/B knob)
-    bool fused_scatter;   // scatter from inside k_bp instead of a scatter kernel (A/B knob)
-    int scatter_mode;     // A/B knob: -1 by row layout (default), 0 slab, 1 step-ordered tile, 2 LDS box
+    int scatter_mode;     // A/B knob RAYNET_HIP_SCATTER_MODE: -1 by row layout (default), 0 slab, 2 LDS box
     // LDS-box scatter: chunk length in use (32, or 16 once too many 32-step chunks overflowed),
     // {chunks, overflowed chunks} of the previous launches on the device / pinned host mirror
     int box_steps;
@@ -1387,28 +1289,17 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
     launch_sweep_t<1, 1, 8, MAPMODE, PACKED>(ctx, a, st);
 }
 
+// One BP sweep: k_bp (messages) + the accumulator scatter that fits the row layout.
 template <bool PACKED, bool CLIP_IN>
 int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
               const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
-              int64_t xcd_stride, hipStream_t st, bool patch_rows = false) {
+              hipStream_t st, bool patch_rows = false) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
-    const bool fused = ctx->fused_scatter;
-    // measurement knob: dynamic LDS reserved per block only to cap the occupancy
-    const char *lds_env = getenv("RAYNET_HIP_BP_LDS");
-    const size_t bp_lds = lds_env ? (size_t)atoi(lds_env) : 0;
     {
         ProfScope prof(ctx, RN_K_BP, n, st);
-#define RN_BP(NCH_)                                                                         \
-    do {                                                                                    \
-        if (fused)                                                                          \
-            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, true>), dim3(ray_blocks(n)), \
-                               dim3(BLOCK), bp_lds, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in,  \
-                               acc_out, msgs_out, xcd_stride);                               \
-        else                                                                                \
-            hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, false>),                   \
-                               dim3(ray_blocks(n)), dim3(BLOCK), bp_lds, st, ctx->p, n, Sv,   \
-                               vox, rvc, acc_in, msgs_in, acc_out, msgs_out, xcd_stride);    \
-    } while (0)
+#define RN_BP(NCH_)                                                                            \
+    hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
+                       ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, msgs_out)
         if (nch <= 2) RN_BP(2);
         else if (nch <= 4) RN_BP(4);
         else if (nch <= 6) RN_BP(6);
@@ -1418,41 +1309,31 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
 #undef RN_BP
     }
     RN_LAUNCH_CHECK(ctx);
-    if (!fused) {
-        ProfScope prof(ctx, RN_K_SCATTER, n, st);
-        const int mode = ctx->scatter_mode >= 0 ? ctx->scatter_mode : (patch_rows ? 2 : 0);
-        if (mode == 1)
-            hipLaunchKernelGGL((k_scatter_tile<PACKED>), dim3((n + WAVE - 1) / WAVE), dim3(BLOCK),
-                               0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, xcd_stride);
-        else if (mode == 2)
-        {
-            // previous launches' overflow count (copied out asynchronously, may lag a launch):
-            // more than 2 % of the chunks did not fit -> narrower chunks from now on
-            if (ctx->box_steps == 32 && ctx->box_stats_host[0] > 0 &&
-                ctx->box_stats_host[1] * 50u > ctx->box_stats_host[0])
-                ctx->box_steps = 16;
-            if (ctx->box_steps == 32)
-                hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32>), dim3((n + 127) / 128),
-                                   dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
-                                   xcd_stride, ctx->box_stats);
-            else
-                hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16>), dim3((n + 255) / 256),
-                                   dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
-                                   xcd_stride, (unsigned *)nullptr);
-            if (ctx->box_steps == 32) {
-                (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
-                                     hipMemcpyDeviceToHost, st);
-                (void)hipMemsetAsync(ctx->box_stats, 0, 2 * sizeof(unsigned), st);
-            }
+    ProfScope prof(ctx, RN_K_SCATTER, n, st);
+    const bool box = ctx->scatter_mode >= 0 ? ctx->scatter_mode == 2 : patch_rows;
+    if (box) {
+        // previous launches' overflow count (copied out asynchronously, may lag a launch):
+        // more than 2 % of the chunks did not fit -> narrower chunks from now on
+        if (ctx->box_steps == 32 && ctx->box_stats_host[0] > 0 &&
+            ctx->box_stats_host[1] * 50u > ctx->box_stats_host[0])
+            ctx->box_steps = 16;
+        if (ctx->box_steps == 32) {
+            hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32>), dim3((n + 127) / 128), dim3(BLOCK),
+                               0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
+            (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
+                                 hipMemcpyDeviceToHost, st);
+            (void)hipMemsetAsync(ctx->box_stats, 0, 2 * sizeof(unsigned), st);
+        } else {
+            hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16>), dim3((n + 255) / 256), dim3(BLOCK),
+                               0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, (unsigned *)nullptr);
         }
-        else
-            hipLaunchKernelGGL((k_scatter_slab<PACKED>),
-                               dim3(((n + WAVE - 1) / WAVE) *
-                                    ((ctx->p.M + SLAB_STEPS - 1) / SLAB_STEPS)),
-                               dim3(WAVE), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
-                               xcd_stride);
-        RN_LAUNCH_CHECK(ctx);
+    } else {
+        hipLaunchKernelGGL((k_scatter_slab<PACKED>),
+                           dim3(((n + WAVE - 1) / WAVE) *
+                                ((ctx->p.M + SLAB_STEPS - 1) / SLAB_STEPS)),
+                           dim3(WAVE), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out);
     }
+    RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }
 
@@ -1526,14 +1407,8 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     p.Hf = cfg->H + cfg->padding + 1;
     p.Wf = cfg->W + cfg->padding + 1;
     for (int i = 0; i < 6; i++) p.bbox[i] = cfg->bbox[i];
-    // RAYNET_HIP_ACC_MODE / RAYNET_HIP_FUSED_SCATTER: measurement knobs, see rn_ctx
-    const char *am = getenv("RAYNET_HIP_ACC_MODE");
-    ctx->acc_mode = am ? atoi(am) : 0;
-    if (ctx->acc_mode < 0 || ctx->acc_mode > 1) ctx->acc_mode = 0;
-    ctx->fused_scatter = getenv("RAYNET_HIP_FUSED_SCATTER") != nullptr;
     const char *sm = getenv("RAYNET_HIP_SCATTER_MODE");
     ctx->scatter_mode = sm ? atoi(sm) : -1;
-    ctx->copies = ctx->acc_mode == 0 ? 1 : NXCD;
     const char *bs = getenv("RAYNET_HIP_BOX_STEPS");      // A/B knob: pin the chunk length
     ctx->box_steps = bs && atoi(bs) == 16 ? 16 : 32;
     if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
@@ -1676,7 +1551,7 @@ int rn_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sv, const int32_t *rvi, con
     if (!ctx || n < 0 || !Sv || !rvi || !rvc || !acc_in || !acc_out || !msgs_out)
         return fail(ctx, RN_ERR_INVALID, "bad argument");   /* msgs_in == NULL: all-zero messages */
     if (n == 0) return RN_OK;
-    return launch_bp<false, true>(ctx, n, Sv, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
+    return launch_bp<false, true>(ctx, n, Sv, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out,
                                   S(stream));
 }
 
@@ -1781,7 +1656,7 @@ int rn_fused_bp_sweep(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const flo
     rc = prefix_api(ctx, n, ray_idxs, features, P, P_inv, camera_center, rvi, rvc, S_voxel,
                     S(stream));
     if (rc) return rc;
-    return launch_bp<false, true>(ctx, n, S_voxel, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
+    return launch_bp<false, true>(ctx, n, S_voxel, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out,
                                   S(stream));
 }
 
@@ -1805,7 +1680,7 @@ int rn_fused_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float 
 }
 
 // ------------------------------------------------------ resident-scene path
-int rn_acc_copies(const rn_ctx *ctx) { return ctx ? ctx->copies : 0; }
+int rn_acc_copies(const rn_ctx *ctx) { return ctx ? 1 : 0; }
 
 int64_t rn_acc_size(const rn_ctx *ctx) { return ctx ? acc_floats(ctx) : 0; }
 
@@ -1899,10 +1774,8 @@ int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vo
     if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc_in || !msgs || !acc_part)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
-    const int64_t G = acc_floats(ctx);
     return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, first_sweep ? nullptr : msgs,
-                                  acc_part, msgs, ctx->acc_mode == 1 ? G : 0, S(stream),
-                                  row_layout == RN_ROWS_PATCHES);
+                                  acc_part, msgs, S(stream), row_layout == RN_ROWS_PATCHES);
 }
 
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream) {
@@ -1910,7 +1783,7 @@ int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, vo
     const int64_t G = acc_floats(ctx);
     ProfScope prof(ctx, RN_K_ACC, 0, S(stream));
     hipLaunchKernelGGL(k_acc_combine, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream), acc_part,
-                       ctx->copies, G, prior, acc_out, 1);
+                       1, G, prior, acc_out, 1);
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }
@@ -1920,7 +1793,7 @@ int rn_acc_reduce_local(rn_ctx *ctx, float *acc_part, float *acc_out, void *stre
     const int64_t G = acc_floats(ctx);
     ProfScope prof(ctx, RN_K_ACC, 0, S(stream));
     hipLaunchKernelGGL(k_acc_combine, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream), acc_part,
-                       ctx->copies, G, 0.0f, acc_out, 0);
+                       1, G, 0.0f, acc_out, 0);
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }

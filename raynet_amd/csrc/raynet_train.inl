@@ -242,7 +242,7 @@ int rn_train_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *rv
     if (ctx && n == 0) return RN_OK;
     if (!ctx || n < 0 || !Sr || !rvi || !rvc || !acc_in || !acc_out || !msgs_out)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
-    return launch_bp<false, false>(ctx, n, Sr, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out, 0,
+    return launch_bp<false, false>(ctx, n, Sr, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out,
                                    S(stream));
 }
 
