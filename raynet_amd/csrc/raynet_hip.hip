@@ -1165,9 +1165,10 @@ struct rn_ctx {
     float *axes;          // device, gx+gy+gz
     bool have_axes;
     int scatter_mode;     // A/B knob RAYNET_HIP_SCATTER_MODE: -1 by row layout (default), 0 slab, 2 LDS box
-    // LDS-box scatter: chunk length in use (32, or 16 once too many 32-step chunks overflowed),
-    // {chunks, overflowed chunks} of the previous launches on the device / pinned host mirror
-    int box_steps;
+    // LDS-box scatter: tile shape in use (0: 128 rays x 32 steps, 1: 256 x 16, 2: gave up, slab
+    // scatter), {chunks, overflowed chunks} of the previous launches on the device and its
+    // pinned host mirror
+    int box_level;
     unsigned *box_stats, *box_stats_host;
     hipEvent_t ev0, ev1;
     // per-launch profiling (rn_prof_begin / rn_prof_end)
@@ -1310,28 +1311,38 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     }
     RN_LAUNCH_CHECK(ctx);
     ProfScope prof(ctx, RN_K_SCATTER, n, st);
-    const bool box = ctx->scatter_mode >= 0 ? ctx->scatter_mode == 2 : patch_rows;
-    if (box) {
-        // previous launches' overflow count (copied out asynchronously, may lag a launch):
-        // more than 2 % of the chunks did not fit -> narrower chunks from now on
-        if (ctx->box_steps == 32 && ctx->box_stats_host[0] > 0 &&
-            ctx->box_stats_host[1] * 50u > ctx->box_stats_host[0])
-            ctx->box_steps = 16;
-        if (ctx->box_steps == 32) {
-            hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32>), dim3((n + 127) / 128), dim3(BLOCK),
-                               0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
-            (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
-                                 hipMemcpyDeviceToHost, st);
-            (void)hipMemsetAsync(ctx->box_stats, 0, 2 * sizeof(unsigned), st);
-        } else {
-            hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16>), dim3((n + 255) / 256), dim3(BLOCK),
-                               0, st, ctx->p, n, msgs_out, vox, rvc, acc_out, (unsigned *)nullptr);
+    // Patch-ordered rows start with the LDS-box scatter on 128-ray x 32-step tiles.  The
+    // kernel counts the chunks whose bounding box did not fit its LDS budget; the count of
+    // the previous launches is copied out asynchronously (it may lag a launch) and when more
+    // too many overflowed the tile shape steps down: 256 x 16, then -- pixel spacing above
+    // the voxel size, nothing to sum per voxel anyway -- the slab-ordered scatter.
+    int level = ctx->scatter_mode == 0 ? 2 : (ctx->scatter_mode == 2 || patch_rows) ? 0 : 2;
+    if (level == 0) {
+        // 128 x 32 -> 256 x 16 above 2 % overflow; 256 x 16 -> slab only above 25 % (its
+        // quarter-chunk fallback still beats the slab scatter on patch-ordered rows below that)
+        const unsigned per = ctx->box_level == 0 ? 50u : 4u;
+        if (ctx->box_level < 2 && ctx->box_stats_host[0] > 0 &&
+            ctx->box_stats_host[1] * per > ctx->box_stats_host[0]) {
+            ctx->box_level++;
+            ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
         }
-    } else {
+        level = ctx->box_level;
+    }
+    if (level == 0)
+        hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32>), dim3((n + 127) / 128), dim3(BLOCK), 0,
+                           st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
+    else if (level == 1)
+        hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16>), dim3((n + 255) / 256), dim3(BLOCK), 0,
+                           st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
+    else
         hipLaunchKernelGGL((k_scatter_slab<PACKED>),
                            dim3(((n + WAVE - 1) / WAVE) *
                                 ((ctx->p.M + SLAB_STEPS - 1) / SLAB_STEPS)),
                            dim3(WAVE), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out);
+    if (level < 2) {
+        (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
+                             hipMemcpyDeviceToHost, st);
+        (void)hipMemsetAsync(ctx->box_stats, 0, 2 * sizeof(unsigned), st);
     }
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
@@ -1409,8 +1420,8 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     for (int i = 0; i < 6; i++) p.bbox[i] = cfg->bbox[i];
     const char *sm = getenv("RAYNET_HIP_SCATTER_MODE");
     ctx->scatter_mode = sm ? atoi(sm) : -1;
-    const char *bs = getenv("RAYNET_HIP_BOX_STEPS");      // A/B knob: pin the chunk length
-    ctx->box_steps = bs && atoi(bs) == 16 ? 16 : 32;
+    const char *bs = getenv("RAYNET_HIP_BOX_LEVEL");      // A/B knob: start at this tile shape
+    ctx->box_level = bs ? max(0, min(2, atoi(bs))) : 0;
     if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
         hipMalloc(&ctx->box_stats, 2 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc(&ctx->box_stats_host, 2 * sizeof(unsigned)) != hipSuccess ||
