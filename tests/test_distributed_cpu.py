@@ -20,7 +20,7 @@ from conftest import REPO
 H, W, D, M, GRID, VIEWS = 12, 16, 8, 48, (16, 16, 16), 3
 
 
-def _run(rank, world, port, out_dir):
+def _run(rank, world, port, out_dir, filtered=False):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from host_backend import OracleBackend
@@ -35,10 +35,20 @@ def _run(rank, world, port, out_dir):
     gp = GenerationParameters(depth_planes=D, neighbors=VIEWS - 1,
                               grid_shape=np.array(GRID, np.int32),
                               max_number_of_marched_voxels=M, padding=5, gamma_mrf=0.05)
+    if filtered:
+        # filter_out_rays (forward_pass.py:156-165): only pixels with ground truth are cast
+        rng = np.random.default_rng(5)
+        masks = [(rng.random((H, W)) > 0.35).astype(np.float32) for _ in range(VIEWS)]
+        type(scene).get_depth_map = lambda self, i: masks[i]
     fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 50,
+                                            filter_out_rays=filtered,
                                             backend_factory=OracleBackend)
     depths = list(fp.forward_pass(scene, (0, VIEWS, 1)))
-    np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), depth=np.stack(depths),
+    if filtered:
+        for d, m in zip(depths, masks):
+            assert (d[m == 0] == 0).all() and (d[m != 0] > 0).all()
+    tag = "f" if filtered else ""
+    np.savez(os.path.join(out_dir, "%sw%d_r%d.npz" % (tag, world, rank)), depth=np.stack(depths),
              acc=fp.accumulator.numpy())
     if world > 1:
         dist.destroy_process_group()
@@ -67,3 +77,18 @@ def test_two_rank_forward_pass_matches_single_rank(tmp_path):
     assert np.abs(one["acc"] - r0["acc"]).max() < 1e-4
     assert (np.abs(one["depth"] - r0["depth"]) > 1e-4).mean() < 0.01
     assert np.isfinite(r0["acc"]).all() and (r0["depth"] > 0).all()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_filtered_rays_and_patch_rows(tmp_path):
+    """The same with `filter_out_rays`: every rank tile-orders the SAME ragged ray list, owns a
+    contiguous slice of it, and the merged maps put the depths back at their pixels."""
+    out = str(tmp_path)
+    _run(0, 1, 0, out, True)
+    mp.spawn(_run, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    one = np.load(os.path.join(out, "fw1_r0.npz"))
+    r0 = np.load(os.path.join(out, "fw2_r0.npz"))
+    r1 = np.load(os.path.join(out, "fw2_r1.npz"))
+    assert np.array_equal(r0["depth"], r1["depth"]) and np.array_equal(r0["acc"], r1["acc"])
+    assert np.abs(one["acc"] - r0["acc"]).max() < 1e-4
+    assert (np.abs(one["depth"] - r0["depth"]) > 1e-4).mean() < 0.01
