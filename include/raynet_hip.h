@@ -297,6 +297,32 @@ int rn_train_depth_bwd(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *r
                        const float *g_S_new, float *g_Sr, float *g_acc, float *g_msgs,
                        void *stream);
 
+/* ---- consumers of the depth maps ----------------------
+ * Pixel i = u*H + v (column-major, common/image.py:252-255), depth maps are [H][W] f32 as
+ * the forward pass writes them (scripts/forward_pass.py:136-142); matrices and points are
+ * float64 like the NumPy code these entry points restate. */
+
+/* raynet/pointcloud.py:121-147 (_generate_points_per_image without the pixel selection):
+ * points [3][H*W] f64 = centre + depth * normalised ray direction, for every pixel.
+ * P_pinv [4][3], camera_center [4] (device). */
+int rn_depthmap_points(rn_ctx *ctx, int32_t H, int32_t W, const double *P_pinv,
+                       const double *camera_center, const float *depth_map, double *points,
+                       void *stream);
+
+/* One neighbour view of raynet/pointcloud.py:205-245: tau[i] = max(tau[i], |depth_map at the
+ * point's projection - distance of the point to that camera|), inf where the projection
+ * falls outside the view; first != 0 starts tau.  points [3][n] f64, P [3][4]. */
+int rn_consistency_tau(rn_ctx *ctx, int32_t n, int32_t H, int32_t W, int32_t first,
+                       const double *points, const double *P, const double *camera_center,
+                       const float *depth_map, double *tau, void *stream);
+
+/* Exact nearest neighbours (the KDTree.query of raynet/pointcloud.py:63-72, behind
+ * Accuracy / Completeness, metrics.py:155-236): for every query point the distance to and
+ * the index of the closest reference point (either output may be NULL).  Points are
+ * [n][4] f32 (x, y, z, unused). */
+int rn_nearest_neighbors(rn_ctx *ctx, int32_t n_ref, const float *ref_xyzw, int32_t n_query,
+                         const float *query_xyzw, float *dist, int32_t *idx, void *stream);
+
 /* hipEvent pair on `stream`; rn_timer_stop returns elapsed milliseconds after
  * synchronising on the stop event (bench.py's per-kernel timing). */
 int rn_timer_start(rn_ctx *ctx, void *stream);

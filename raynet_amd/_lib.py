@@ -31,7 +31,7 @@ class RaynetHipError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "raynet_hip.hip"), os.path.join(CSRC, "raynet_kernels.h"),
-            os.path.join(CSRC, "raynet_train.inl"), HEADER]
+            os.path.join(CSRC, "raynet_train.inl"), os.path.join(CSRC, "raynet_eval.inl"), HEADER]
     if not force and os.path.exists(LIB_PATH) and \
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -98,6 +98,9 @@ SIGNATURES = {
     "rn_train_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _P],
     "rn_train_bp_sweep_bwd": [_P, _I] + [_P] * 11,
     "rn_train_depth_bwd": [_P, _I] + [_P] * 10,
+    "rn_depthmap_points": [_P, _I, _I, _P, _P, _P, _P, _P],
+    "rn_consistency_tau": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "rn_nearest_neighbors": [_P, _I, _P, _I, _P, _P, _P, _P],
     "rn_prof_offsets": [_P, _P],
     "rn_timer_start": [_P, _P],
     "rn_timer_stop": [_P, _P, ctypes.POINTER(_F)],

@@ -1280,7 +1280,7 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
         switch (p.N) {
 #define RN_CASE(NV_)                                                  \
     case NV_:                                                         \
-        launch_sweep_t<2, NV_, 8, MAPMODE, PACKED>(ctx, a, st);       \
+        launch_sweep_t<2, NV_, 8 / RN_SWEEP_V4, MAPMODE, PACKED>(ctx, a, st);       \
         return;
             RN_CASE(2) RN_CASE(3) RN_CASE(4) RN_CASE(5) RN_CASE(6) RN_CASE(7) RN_CASE(8) RN_CASE(9)
 #undef RN_CASE
@@ -1910,3 +1910,6 @@ int rn_timer_stop(rn_ctx *ctx, void *stream, float *ms_out) {
 
 // training (differentiable) entry points, SURVEY.md 8f row 2
 #include "raynet_train.inl"
+
+// depth maps -> point cloud -> accuracy / completeness, SURVEY.md 8f row 3
+#include "raynet_eval.inl"

@@ -208,16 +208,20 @@ __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureView
     }
 }
 
-// Cooperative plane sweep for F = 4*LPS: LPS lanes fetch one 16*LPS-byte feature
-// vector as one contiguous segment (a whole 128-B line for F=32), 64/LPS planes per
-// load instruction.  Each lane multiplies its 4 channels for all view pairs, the
-// LPS partial sums are folded with an xor butterfly.
+// Cooperative plane sweep for F = 4*V4*LPS: LPS lanes fetch one feature vector as one
+// contiguous segment (a whole 128-B line for F=32), 16*V4 bytes per lane, 64/LPS planes per
+// load round.  Each lane multiplies its 4*V4 channels for all view pairs, the LPS partial
+// sums are folded with an xor butterfly.
+#ifndef RN_SWEEP_V4
+#define RN_SWEEP_V4 1
+#endif
 template <int NV, int LPS>
 __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &fv,
                                            const float *const *__restrict__ tbl,
                                            const float *__restrict__ P, const float s[3],
                                            const float e[3], int lane, float *Sl) {
-    constexpr int SPL = WAVE / LPS;       // planes per load instruction
+    constexpr int SPL = WAVE / LPS;       // planes per load round
+    constexpr int V4 = RN_SWEEP_V4;       // float4s per lane and view
     const float *vbase[NV];               // uniform per-view bases (kernel argument or table)
 #pragma unroll
     for (int v = 0; v < NV; v++) vbase[v] = tbl ? tbl[v] : fv.v[v];
@@ -238,40 +242,48 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
 #pragma unroll 2
         for (int it = 0; it < LPS; it++) {
             const int src = it * SPL + sub;   // plane (within the chunk) this lane helps with
-            // lane's 16 bytes of every view's vector, as two channel pairs: the packed FMAs
-            // below then work on the register pairs exactly as the loads deliver them
-            float2v flo[NV], fhi[NV];
+            // lane's 16*V4 bytes of every view's vector, as channel pairs: the packed FMAs below
+            // then work on the register pairs exactly as the loads deliver them
+            float2v f2[NV][2 * V4];
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                // byte offset from a uniform GLOBAL base: one load with a 32-bit register
-                // offset (global_load ... s[base]), no 64-bit address arithmetic per lane
-                const unsigned ob = (unsigned)__shfl(offb[v], src) + 16u * (unsigned)part;
+                // byte offset from a uniform GLOBAL base: loads with a 32-bit register offset
+                // (global_load ... s[base]), no 64-bit address arithmetic per lane
+                const unsigned ob = (unsigned)__shfl(offb[v], src) + (16u * V4) * (unsigned)part;
                 typedef const __attribute__((address_space(1))) char *gptr;
                 typedef const __attribute__((address_space(1))) float4v *gptr4;
-                const float4v f = *(gptr4)((gptr)vbase[v] + ob);
-                flo[v] = float2v{f.x, f.y};
-                fhi[v] = float2v{f.z, f.w};
+#pragma unroll
+                for (int q = 0; q < V4; q++) {
+                    const float4v f = *(gptr4)((gptr)vbase[v] + ob + 16u * q);
+                    f2[v][2 * q] = float2v{f.x, f.y};
+                    f2[v][2 * q + 1] = float2v{f.z, f.w};
+                }
             }
             // sum over view pairs i<j of <f_i, f_j>, as  sum_j <f_0 + ... + f_{j-1}, f_j>  on this
-            // lane's 4 channels: NV-1 packed FMAs and NV-2 packed adds per channel pair instead
+            // lane's channels: NV-1 packed FMAs and NV-2 packed adds per channel pair instead
             // of NV(NV-1)/2 products.  This is the only place where multiply-adds may fuse and
             // where the summation order departs from the reference's serial pair loop (the
             // kernels are VALU-issue bound; tolerance-tested against the oracle).
             float acc;
             {
 #pragma clang fp contract(fast)
-                float2v rlo = flo[0], rhi = fhi[0];
-                float2v alo = float2v{0.f, 0.f}, ahi = float2v{0.f, 0.f};
+                float2v run[2 * V4], a2[2 * V4];
+#pragma unroll
+                for (int c = 0; c < 2 * V4; c++) {
+                    run[c] = f2[0][c];
+                    a2[c] = float2v{0.f, 0.f};
+                }
 #pragma unroll
                 for (int j = 1; j < NV; j++) {
-                    alo = rlo * flo[j] + alo;
-                    ahi = rhi * fhi[j] + ahi;
-                    if (j + 1 < NV) {
-                        rlo += flo[j];
-                        rhi += fhi[j];
+#pragma unroll
+                    for (int c = 0; c < 2 * V4; c++) {
+                        a2[c] = run[c] * f2[j][c] + a2[c];
+                        if (j + 1 < NV) run[c] += f2[j][c];
                     }
                 }
-                const float2v t = alo + ahi;
+                float2v t = a2[0];
+#pragma unroll
+                for (int c = 1; c < 2 * V4; c++) t += a2[c];
                 acc = t.x + t.y;
             }
 #pragma unroll

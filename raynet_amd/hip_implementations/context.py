@@ -148,6 +148,22 @@ class HipContext(object):
             self._h, len(rvc), _ptr(Sr), _ptr(rvi), _ptr(rvc), _ptr(acc), _ptr(msgs),
             _ptr(g_S_new), _ptr(g_Sr), _ptr(g_acc), _ptr(g_msgs), _stream()))
 
+    # ---- consumers of the depth maps (point clouds, metrics) --------------------------
+    def depthmap_points(self, H, W, P_pinv, center, depth_map, points):
+        self._check(self.lib.rn_depthmap_points(self._h, int(H), int(W), _ptr(P_pinv), _ptr(center),
+                                                _ptr(depth_map), _ptr(points), _stream()))
+
+    def consistency_tau(self, H, W, first, points, P, center, depth_map, tau):
+        self._check(self.lib.rn_consistency_tau(self._h, points.shape[1], int(H), int(W),
+                                                1 if first else 0, _ptr(points), _ptr(P),
+                                                _ptr(center), _ptr(depth_map), _ptr(tau),
+                                                _stream()))
+
+    def nearest_neighbors(self, ref_xyzw, query_xyzw, dist, idx=None):
+        self._check(self.lib.rn_nearest_neighbors(self._h, ref_xyzw.shape[0], _ptr(ref_xyzw),
+                                                  query_xyzw.shape[0], _ptr(query_xyzw),
+                                                  _ptr(dist), _ptr(idx), _stream()))
+
     KERNEL_NAMES = {1: "traverse", 2: "sweep_map", 3: "bp", 4: "depth", 5: "acc", 6: "other", 7: "scatter"}
 
     def prof_begin(self, capacity=4096):
