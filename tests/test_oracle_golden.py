@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import REPO, load_cases
+from conftest import GOLDEN, REPO, load_cases
 
 TRAV = load_cases("ref_traversal.npz")
 MRF = load_cases("ref_mrf_np.npz")
@@ -199,3 +199,26 @@ def test_config1_cpu_plumbing(oracle_mod):
     assert np.abs(S_new[hit].sum(1) - 1).max() < 1e-4
     # the cameras fly ~17 units from the site
     assert 10 < np.median(depth[hit]) < 25
+
+
+def test_neighbour_view_rule_matches_reference():
+    """get_adjacent_frames_idxs against the table the reference's own function produced
+    (tests/golden/gen_adjacent_frames_from_reference.py), plus the assertions of the
+    reference's tests/test_scene.py:120-128."""
+    import json
+    import warnings
+    from raynet_amd.common.scene import adjacent_views, get_adjacent_frames_idxs
+    table = json.load(open(os.path.join(GOLDEN, "ref_adjacent_frames.json")))
+    assert len(table) > 600
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                  # the rule's own uint32 wrap-arounds
+        for ref_idx, n_frames, n_adjacent, skip, expected in table:
+            try:
+                got = [int(v) for v in get_adjacent_frames_idxs(ref_idx, n_frames, n_adjacent, skip)]
+            except Exception as e:                       # noqa: BLE001
+                got = "error:" + type(e).__name__
+            assert got == expected, (ref_idx, n_frames, n_adjacent, skip, got, expected)
+    assert adjacent_views(0, 50, 4) == [1, 2, 3, 4]
+    assert adjacent_views(1, 50, 4) == [0, 2, 3, 4]
+    assert adjacent_views(35, 50, 4) == [33, 34, 36, 37]
+    assert adjacent_views(50, 50, 4) == [46, 47, 48, 49]
