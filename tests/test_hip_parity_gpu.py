@@ -761,3 +761,46 @@ def test_box_scatter_with_caller_made_voxel_lists(torch, oracle_mod):
     assert np.isfinite(m).all()
     got = ctx.acc_to_grid(part.sum(0)).cpu().numpy()
     assert np.abs(got - truth).max() < 1e-5 * max(1.0, np.abs(truth).max())
+
+
+def test_maximum_sizes_m1024(torch, oracle_mod):
+    """M = 1024 (the library's maximum: 16 register chunks) on a grid with a 1000-voxel axis,
+    so that rays really have ~1000 voxels: K3 / K4 against the oracle; and the limits
+    rn_create refuses."""
+    from raynet_amd import _lib
+    from raynet_amd.hip_implementations import get_context, HipContext
+    M, D, grid = 1024, 8, (1000, 4, 4)
+    bbox = np.array([-10, -0.04, -0.04, 10, 0.04, 0.04], np.float32)
+    o = oracle_mod.Oracle(M=M, D=D, N=2, F=4, H=4, W=4, padding=3, bbox=bbox, grid_shape=grid)
+    n = 70
+    rng = np.random.default_rng(2)
+    starts = np.c_[-10 * np.ones(n), rng.uniform(-0.03, 0.03, (n, 2))].astype(np.float32)
+    ends = np.c_[10 * np.ones(n), rng.uniform(-0.03, 0.03, (n, 2))].astype(np.float32)
+    ends[:10, 0] = rng.uniform(-9, 9, 10)             # some shorter rays
+    rvi, rvc = o.traversal(starts, ends)
+    assert rvc.max() >= 1000 and rvc.min() > 10
+    S = rng.random((n, M)).astype(np.float32) + 0.01
+    S *= np.arange(M)[None, :] < rvc[:, None]
+    S /= S.sum(1, keepdims=True)
+    ctx = get_context(M, D, 2, 4, 4, 4, 3, bbox, grid)
+    dev = "cuda"
+    rvi_d, rvc_d = torch.from_numpy(rvi).to(dev), torch.from_numpy(rvc).to(dev)
+    prior = o.prior(0.05)
+    acc_in = torch.from_numpy(prior).to(dev)
+    acc_out = torch.from_numpy(prior.copy()).to(dev)
+    msgs = torch.zeros((n, M), device=dev)
+    ctx.bp_sweep(torch.from_numpy(S).to(dev), rvi_d, rvc_d, acc_in, msgs, acc_out, msgs)
+    acc_o, msgs_o = prior.copy(), np.zeros((n, M), np.float32)
+    o.bp_sweep(S, rvi, rvc, prior, msgs_o, acc_o)
+    assert np.all(np.abs(msgs.cpu().numpy() - msgs_o) <= logit_tol(msgs_o) * 8)
+    assert np.abs(acc_out.cpu().numpy() - acc_o).max() <= 1e-3
+    S_new = torch.zeros((n, M), device=dev)
+    ctx.depth_estimation(torch.from_numpy(S).to(dev), rvi_d, rvc_d, torch.from_numpy(acc_o).to(dev),
+                         torch.from_numpy(msgs_o).to(dev), S_new)
+    assert np.abs(S_new.cpu().numpy() - o.depth_distribution(S, rvi, rvc, acc_o, msgs_o)).max() <= 1e-5
+    # limits: M > 1024, a grid axis > 1024, feature maps beyond 32-bit byte offsets
+    for kw in (dict(M=1025), dict(grid_shape=(1025, 4, 4)), dict(H=20000, W=20000, F=32)):
+        args = dict(M=8, D=8, N=2, F=4, H=4, W=4, padding=3, bbox=bbox, grid_shape=(4, 4, 4))
+        args.update(kw)
+        with pytest.raises(_lib.RaynetHipError):
+            HipContext(**args)
