@@ -88,16 +88,23 @@ def sweep_order(ray_idxs, H, W, images):
     return None
 
 
-def tile_order(ray_idxs, H, W, tile_x, tile_y):
+def tile_order(ray_idxs, H, W, tile_x, tile_y, along_rows=False):
     """The ray list (idx = x*H + y, sampling_schemes.cu:5-8) re-ordered into tile_x x tile_y
     pixel patches: consecutive rows of the per-ray buffers are then neighbouring rays in BOTH
-    image directions, so a scatter tile of 256 rows sums ~13 rays per voxel in LDS before it
-    touches the accumulator (k_scatter_box).  Row order never changes results -- every
-    per-ray quantity is computed from the ray index -- only where a ray's row lives."""
+    image directions, so a scatter tile sums ~11 rays per voxel in LDS before it touches the
+    accumulator (k_scatter_box).  along_rows: patches (and the pixels inside them) are
+    enumerated along image rows instead of columns -- the rays a GPU works on at the same
+    time then share the epipolar lines of neighbour views that lie along image rows (see
+    sweep_direction).  Row order never changes results -- every per-ray quantity is computed
+    from the ray index -- only where a ray's row lives."""
     idx = ray_idxs.to(torch.int64)
     x, y = idx // H, idx % H
-    tiles_y = (H + tile_y - 1) // tile_y
-    key = (((x // tile_x) * tiles_y + y // tile_y) * tile_x + x % tile_x) * tile_y + y % tile_y
+    if along_rows:
+        tiles_x = (W + tile_x - 1) // tile_x
+        key = (((y // tile_y) * tiles_x + x // tile_x) * tile_y + y % tile_y) * tile_x + x % tile_x
+    else:
+        tiles_y = (H + tile_y - 1) // tile_y
+        key = (((x // tile_x) * tiles_y + y // tile_y) * tile_x + x % tile_x) * tile_y + y % tile_y
     return ray_idxs[torch.argsort(key)].to(torch.int32).contiguous()
 
 
@@ -396,19 +403,25 @@ class RayNetForwardPass(ForwardPass):
         shards = []
         lists = {}
         patch_rows = self.ray_tile is not None
+        # patches are enumerated along the direction of the neighbour views' epipolar lines
+        # (of the first reference image: one list serves the whole scene)
+        along = os.environ.get("RAYNET_TILE_ALONG", "auto")
+        along_rows = patch_rows and bool(refs) and (
+            along == "rows" or (along == "auto" and sweep_direction(
+                H, W, [scene.get_image(v) for v in views_of[refs[0]]]) == "rows"))
         for k, r in enumerate(refs):
             # the image's ray list in ROW order (what row i of its buffers holds)
             if self._filter_out_rays:
                 rays = ctx.dev(np.ascontiguousarray(
                     self.get_valid_rays_per_image(scene, r).astype(np.int32)))
                 if patch_rows:
-                    rays = tile_order(rays, H, W, *self.ray_tile)
+                    rays = tile_order(rays, H, W, *self.ray_tile, along_rows=along_rows)
             else:       # all H*W rays (forward_pass.py:166-168): built on the device, once
-                key = (H, W, self.ray_tile, str(dev))
+                key = (H, W, self.ray_tile, along_rows, str(dev))
                 if key not in self._ray_lists:
                     rays = torch.arange(H * W, dtype=torch.int32, device=dev)
                     if patch_rows:
-                        rays = tile_order(rays, H, W, *self.ray_tile)
+                        rays = tile_order(rays, H, W, *self.ray_tile, along_rows=along_rows)
                     self._ray_lists[key] = rays
                 rays = self._ray_lists[key]
             total = len(rays)
