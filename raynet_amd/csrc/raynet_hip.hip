@@ -556,10 +556,11 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
         if (ch * WAVE < count) {
             const int i = ch * WAVE + lane;
             if (i < count) {
-                float pos = cex[ch] + tsv[ch];
+                // log p - log(1 - p) with p = pos / (pos + neg) (mrf_bp.cu:160-165) is
+                // log pos - log neg: no normalisation, and no cancellation in 1 - p
+                const float pos = cex[ch] + tsv[ch];
                 const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
-                pos = bp_div(pos, pos + neg);
-                const float m = bp_log(pos) - bp_log(1.0f - pos);
+                const float m = bp_log(pos) - bp_log(neg);
                 mout_row[i] = m;
             }
         }
