@@ -45,6 +45,10 @@ CONFIGS = {
                     workload="synthetic 9-view scene, 640x480, 128 depth planes, 256^3 voxels"),
     "small": dict(H=120, W=160, views=5, D=64, M=384, grid=(128, 128, 128), F=32, padding=11,
                   workload="reduced 120x160 (debug only)"),
+    # one eighth of config 2's rays per image at the same pixel density: what one rank of an
+    # 8-GPU run has to do (debug only; no collectives)
+    "eighth": dict(H=480, W=80, views=5, D=64, M=384, grid=(128, 128, 128), F=32, padding=11,
+                   workload="480x80 strip of config 2 (debug only)"),
 }
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)

@@ -222,6 +222,18 @@ typedef enum { RN_ROWS_LINEAR = 0, RN_ROWS_PATCHES = 1 } rn_row_layout;
 int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                       const int32_t *rvc, const float *acc_in, float *msgs, float *acc_part,
                       int32_t first_sweep, int32_t row_layout, void *stream);
+/* Deterministic mode: the same sweep, but every message is turned into a
+ * signed 31.32 fixed-point integer and summed with 64-bit integer additions in LDS and in
+ * acc_part_fixed [rn_acc_size()] i64 (zero before the first sweep of an iteration).  Integer
+ * addition is associative: the accumulator is bit-identical from run to run, and -- with the
+ * partials of several GPUs summed as int64 -- for any number of ranks.
+ * rn_acc_combine_fixed: acc_out = prior + acc_part_fixed * 2^-32, and zeroes the partial. */
+int rn_scene_bp_sweep_fixed(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
+                            const int32_t *rvc, const float *acc_in, float *msgs,
+                            int64_t *acc_part_fixed, int32_t first_sweep, int32_t row_layout,
+                            void *stream);
+int rn_acc_combine_fixed(rn_ctx *ctx, int64_t *acc_part_fixed, float prior, float *acc_out,
+                         void *stream);
 /* acc_out = prior + sum over copies (+ optionally `extra`, e.g. nothing or a
  * peer's partial); the copies are zeroed for the next iteration. */
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream);

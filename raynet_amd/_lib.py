@@ -87,6 +87,8 @@ SIGNATURES = {
     "rn_acc_to_grid": [_P, _P, _P, _P],
     "rn_acc_from_grid": [_P, _P, _P, _P],
     "rn_scene_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "rn_scene_bp_sweep_fixed": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "rn_acc_combine_fixed": [_P, _P, _F, _P, _P],
     "rn_acc_combine": [_P, _P, _F, _P, _P],
     "rn_acc_reduce_local": [_P, _P, _P, _P],
     "rn_acc_add_prior": [_P, _P, _F, _P],

@@ -818,15 +818,53 @@ constexpr int BOX_CAP = RN_BOX_CAP;      // voxels (doubles of LDS) per chunk
 // overflowed and the launcher looks at the previous launches' count (rn_ctx::box_*).
 __device__ __forceinline__ int wave_reduce_max(int x) { return lane63i(wave_scan_max(x)); }
 __device__ __forceinline__ int wave_reduce_min(int x) { return ~wave_reduce_max(~x); }
-template <bool PACKED, int BOX_RAYS, int BOX_STEPS>
+// What the scatter sums in.  Default: doubles in LDS, float atomics on the accumulator (the
+// reference's float atomicAdd, mrf_bp.cu:170-176).  FIXED: every message becomes a signed
+// 31.32 fixed-point integer first and all sums -- LDS, accumulator, and the all-reduce across
+// GPUs -- are 64-bit integer additions: associative, so the accumulator is bit-identical from
+// run to run and for any number of ranks (SURVEY.md 8e "deterministic mode").
+template <bool FIXED>
+struct AccSum {
+    typedef double box_t;
+    typedef float acc_t;
+    static __device__ __forceinline__ box_t from_msg(float m) { return (double)m; }
+    static __device__ __forceinline__ void direct(acc_t *acc, int lin, float m) {
+        __hip_atomic_fetch_add(acc + lin, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ void flush(acc_t *acc, int lin, box_t v) {
+        const float f = (float)v;
+        if (f != 0.0f) __hip_atomic_fetch_add(acc + lin, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+__device__ __forceinline__ unsigned long long msg_to_fixed(float m) {
+    // m * 2^32 is exact in double; saturate what does not fit (non-finite messages)
+    const double x = fmin(fmax((double)m * 4294967296.0, -9.2e18), 9.2e18);
+    return (unsigned long long)__double2ll_rn(x == x ? x : 0.0);
+}
+template <>
+struct AccSum<true> {
+    typedef unsigned long long box_t;
+    typedef unsigned long long acc_t;
+    static __device__ __forceinline__ box_t from_msg(float m) { return msg_to_fixed(m); }
+    static __device__ __forceinline__ void direct(acc_t *acc, int lin, float m) {
+        __hip_atomic_fetch_add(acc + lin, msg_to_fixed(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ void flush(acc_t *acc, int lin, box_t v) {
+        if (v != 0ull) __hip_atomic_fetch_add(acc + lin, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+template <bool PACKED, int BOX_RAYS, int BOX_STEPS, bool FIXED = false>
 __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                                        const float *__restrict__ msgs,
                                                        const int32_t *__restrict__ vox,
                                                        const int32_t *__restrict__ rvc,
-                                                       float *acc_out,
+                                                       void *acc_out_raw,
                                                        unsigned *overflow_stats) {
+    typedef AccSum<FIXED> Sum;
+    typename Sum::acc_t *acc_out = static_cast<typename Sum::acc_t *>(acc_out_raw);
     constexpr int BOX_NB = BOX_RAYS * BOX_STEPS / BLOCK;     // pairs per thread and chunk
-    __shared__ double box[BOX_CAP];
+    __shared__ typename Sum::box_t box[BOX_CAP];
     __shared__ int red[2][6 * WAVES_PER_BLOCK];
     __shared__ int red_cnt[WAVES_PER_BLOCK];
     __shared__ int cnts[BOX_RAYS];
@@ -883,14 +921,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
         const int sz = BLOCK % d2, ty = BLOCK / d2;
         const int sy = ty % d1, sx = ty / d1;
         for (int i = tid; i < V; i += BLOCK) {
-            const float val = (float)box[i];
-            if (val != 0.0f) {
-#ifdef RN_SCATTER_STATS
-                atomicAdd(&g_scatter_stats[3], 1ull);
-#endif
-                __hip_atomic_fetch_add(acc_out + lin_xyz<PACKED>(p, lo0 + i0, lo1 + i1, lo2 + i2), val,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            Sum::flush(acc_out, lin_xyz<PACKED>(p, lo0 + i0, lo1 + i1, lo2 + i2), box[i]);
             i2 += sz;
             if (i2 >= d2) { i2 -= d2; i1++; }
             i1 += sy;
@@ -935,14 +966,14 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
         }
 #endif
         if (V <= BOX_CAP) {
-            for (int i = tid; i < V; i += BLOCK) box[i] = 0.0;
+            for (int i = tid; i < V; i += BLOCK) box[i] = 0;
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < BOX_NB; k++)
                 if (okmask >> k & 1) {
                     const int x = v[k] >> 20, y = (v[k] >> 10) & 1023, z = v[k] & 1023;
                     __hip_atomic_fetch_add(box + ((x - lo0) * d1 + (y - lo1)) * d2 + (z - lo2),
-                                           (double)m[k], __ATOMIC_RELAXED,
+                                           Sum::from_msg(m[k]), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             __syncthreads();
@@ -975,7 +1006,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             const int e0 = hi0 - lo0 + 1, e1 = hi1 - lo1 + 1, e2 = hi2 - lo2 + 1;
             const bool fits = e0 * e1 * e2 <= BOX_CAP;
             if (fits) {
-                for (int i = tid; i < e0 * e1 * e2; i += BLOCK) box[i] = 0.0;
+                for (int i = tid; i < e0 * e1 * e2; i += BLOCK) box[i] = 0;
                 __syncthreads();
             }
 #pragma unroll 1
@@ -988,11 +1019,10 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                     const int x = pv >> 20, y = (pv >> 10) & 1023, z = pv & 1023;
                     if (fits)
                         __hip_atomic_fetch_add(box + ((x - lo0) * e1 + (y - lo1)) * e2 + (z - lo2),
-                                               (double)mm, __ATOMIC_RELAXED,
+                                               Sum::from_msg(mm), __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
                     else
-                        __hip_atomic_fetch_add(acc_out + lin_of<PACKED>(p, pv), mm,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        Sum::direct(acc_out, lin_of<PACKED>(p, pv), mm);
                 }
             }
             if (fits) {
@@ -1003,6 +1033,34 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
     }
     if (tid == 0 && overflow_stats)
         atomicAdd(overflow_stats, (unsigned)((maxc + BOX_STEPS - 1) / BOX_STEPS));
+}
+
+// deterministic scatter for rows the box kernel is not used on: every (ray, voxel) pair adds
+// its fixed-point message straight to the 64-bit accumulator (slow, order-independent)
+template <bool PACKED>
+__global__ __launch_bounds__(BLOCK) void k_scatter_direct_fixed(Params p, int n,
+                                                                const float *__restrict__ msgs,
+                                                                const int32_t *__restrict__ vox,
+                                                                const int32_t *__restrict__ rvc,
+                                                                unsigned long long *acc_out) {
+    int lane;
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    const int count = min(uniform(rvc[r]), p.M);
+    if (count <= 1) return;
+    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+    for (int i = lane; i < count; i += WAVE)
+        AccSum<true>::direct(acc_out, lin_of<PACKED>(p, load_packed<PACKED>(vrow, i)),
+                             msgs[(size_t)r * p.M + i]);
+}
+// acc_out = prior + fixed-point partial (2^-32 units); the partial is zeroed for the next sweep
+__global__ void k_acc_combine_fixed(unsigned long long *part, int64_t G, float prior, float *out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < G;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double s = (double)(long long)part[i] * (1.0 / 4294967296.0);
+        part[i] = 0ull;
+        out[i] = prior + (float)s;
+    }
 }
 
 // ------------------------------------------------- K4 / K2 tail: depth estimate
@@ -1294,8 +1352,8 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
 // One BP sweep: k_bp (messages) + the accumulator scatter that fits the row layout.
 template <bool PACKED, bool CLIP_IN>
 int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
-              const float *acc_in, const float *msgs_in, float *acc_out, float *msgs_out,
-              hipStream_t st, bool patch_rows = false) {
+              const float *acc_in, const float *msgs_in, void *acc_out, float *msgs_out,
+              hipStream_t st, bool patch_rows = false, bool fixed = false) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     {
         ProfScope prof(ctx, RN_K_BP, n, st);
@@ -1329,17 +1387,30 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
         }
         level = ctx->box_level;
     }
-    if (level == 0)
+    if (level == 0 && !fixed)
         hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32>), dim3((n + 127) / 128), dim3(BLOCK), 0,
                            st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
-    else if (level == 1)
+    else if (level == 0)
+        hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32, true>), dim3((n + 127) / 128),
+                           dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
+                           ctx->box_stats);
+    else if (level == 1 && !fixed)
         hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16>), dim3((n + 255) / 256), dim3(BLOCK), 0,
                            st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
+    else if (level == 1)
+        hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16, true>), dim3((n + 255) / 256),
+                           dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
+                           ctx->box_stats);
+    else if (fixed)
+        hipLaunchKernelGGL((k_scatter_direct_fixed<PACKED>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st,
+                           ctx->p, n, msgs_out, vox, rvc,
+                           static_cast<unsigned long long *>(acc_out));
     else
         hipLaunchKernelGGL((k_scatter_slab<PACKED>),
                            dim3(((n + WAVE - 1) / WAVE) *
                                 ((ctx->p.M + SLAB_STEPS - 1) / SLAB_STEPS)),
-                           dim3(WAVE), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out);
+                           dim3(WAVE), 0, st, ctx->p, n, msgs_out, vox, rvc,
+                           static_cast<float *>(acc_out));
     if (level < 2) {
         (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
                              hipMemcpyDeviceToHost, st);
@@ -1788,6 +1859,29 @@ int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vo
     if (n == 0) return RN_OK;
     return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, first_sweep ? nullptr : msgs,
                                   acc_part, msgs, S(stream), row_layout == RN_ROWS_PATCHES);
+}
+
+int rn_scene_bp_sweep_fixed(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
+                            const int32_t *rvc, const float *acc_in, float *msgs,
+                            int64_t *acc_part_fixed, int32_t first_sweep, int32_t row_layout,
+                            void *stream) {
+    if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
+    if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc_in || !msgs || !acc_part_fixed)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, first_sweep ? nullptr : msgs,
+                                  acc_part_fixed, msgs, S(stream), row_layout == RN_ROWS_PATCHES,
+                                  true);
+}
+
+int rn_acc_combine_fixed(rn_ctx *ctx, int64_t *acc_part_fixed, float prior, float *acc_out,
+                         void *stream) {
+    if (!ctx || !acc_part_fixed || !acc_out) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    const int64_t G = acc_floats(ctx);
+    ProfScope prof(ctx, RN_K_ACC, 0, S(stream));
+    hipLaunchKernelGGL(k_acc_combine_fixed, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream),
+                       reinterpret_cast<unsigned long long *>(acc_part_fixed), G, prior, acc_out);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
 }
 
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream) {

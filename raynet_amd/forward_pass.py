@@ -272,7 +272,7 @@ class RayNetForwardPass(ForwardPass):
 
     def __init__(self, model, generation_params, sampling_scheme, image_shape, rays_batch,
                  filter_out_rays=False, bp_iterations=3, schedule="resident",
-                 reference_quirks=False, backend_factory=None):
+                 reference_quirks=False, backend_factory=None, deterministic=False):
         super(RayNetForwardPass, self).__init__(model, generation_params, sampling_scheme,
                                                 image_shape, rays_batch, filter_out_rays)
         assert schedule in ("resident", "reference")
@@ -284,6 +284,10 @@ class RayNetForwardPass(ForwardPass):
         # world_size-2 gloo test injects a host stand-in to exercise the sharding and
         # all-reduce logic without a GPU.)
         self._backend_factory = backend_factory
+        # deterministic=True: messages are summed as 64-bit fixed-point integers (scatter,
+        # accumulator and the all-reduce across ranks): the accumulator and everything after
+        # it are bit-identical from run to run and for any number of GPUs
+        self.deterministic = deterministic or os.environ.get("RAYNET_DETERMINISTIC", "0") == "1"
         # schedule knob only; results do not depend on it (RAYNET_SWEEP_REORDER=0 for A/B runs)
         self.sweep_reorder = os.environ.get("RAYNET_SWEEP_REORDER", "1") != "0"
         # row layout of the resident buffers: 16x16 pixel patches (RAYNET_RAY_TILE=0: ray-index
@@ -374,7 +378,9 @@ class RayNetForwardPass(ForwardPass):
         G = ctx.acc_size()
         copies = ctx.acc_copies()
         acc_in = torch.full((G,), prior, dtype=torch.float32, device=dev)
-        acc_part = torch.zeros((copies, G), dtype=torch.float32, device=dev)
+        fixed = self.deterministic and hasattr(ctx, "scene_bp_sweep_fixed")
+        acc_part = (torch.zeros((G,), dtype=torch.int64, device=dev) if fixed else
+                    torch.zeros((copies, G), dtype=torch.float32, device=dev))
         acc_next = torch.empty((G,), dtype=torch.float32, device=dev)
 
         # all camera matrices go up in ONE copy before the first launch: a pageable
@@ -491,13 +497,17 @@ class RayNetForwardPass(ForwardPass):
             # iteration 0 starts from zero messages (forward_pass.py:613-615); with the
             # shipped quirk every iteration does (memmap reopened with mode="w+", Q1)
             first = it == 0 or self.reference_quirks
+            sweep = ctx.scene_bp_sweep_fixed if fixed else ctx.scene_bp_sweep
             for i in range(0, n_all, B_all):
-                ctx.scene_bp_sweep(Sr_all[i:i + B_all], vox_all[i:i + B_all],
-                                   rvc_all[i:i + B_all], acc_in, msgs_all[i:i + B_all],
-                                   acc_part, first_sweep=first, patch_rows=patch_rows)
+                sweep(Sr_all[i:i + B_all], vox_all[i:i + B_all], rvc_all[i:i + B_all], acc_in,
+                      msgs_all[i:i + B_all], acc_part, first_sweep=first, patch_rows=patch_rows)
             # swap + prior refill of forward_pass.py:676-678; across ranks the prior is
             # added once, after the sum
-            if world > 1:
+            if fixed:
+                if world > 1:      # integer sum: the same bits whatever the ring order
+                    dist.all_reduce(acc_part, op=dist.ReduceOp.SUM)
+                ctx.acc_combine_fixed(acc_part, prior, acc_next)
+            elif world > 1:
                 ctx.acc_reduce_local(acc_part, acc_next)
                 dist.all_reduce(acc_next, op=dist.ReduceOp.SUM)
                 ctx.acc_add_prior(acc_next, prior)

@@ -295,6 +295,18 @@ class HipContext(object):
                                                1 if first_sweep else 0, 1 if patch_rows else 0,
                                                _stream()))
 
+    def scene_bp_sweep_fixed(self, Sr, vox, rvc, acc_in, msgs, acc_part_fixed, first_sweep=False,
+                             patch_rows=False):
+        assert acc_part_fixed.dtype == torch.int64
+        self._check(self.lib.rn_scene_bp_sweep_fixed(
+            self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc), _ptr(acc_in), _ptr(msgs),
+            _ptr(acc_part_fixed), 1 if first_sweep else 0, 1 if patch_rows else 0, _stream()))
+
+    def acc_combine_fixed(self, acc_part_fixed, prior, acc_out):
+        assert acc_part_fixed.dtype == torch.int64
+        self._check(self.lib.rn_acc_combine_fixed(self._h, _ptr(acc_part_fixed), float(prior),
+                                                  _ptr(acc_out), _stream()))
+
     def acc_combine(self, acc_part, prior, acc_out):
         self._check(self.lib.rn_acc_combine(self._h, _ptr(acc_part), float(prior), _ptr(acc_out),
                                             _stream()))

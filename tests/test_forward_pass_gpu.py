@@ -240,7 +240,7 @@ def test_config1_restrepo_cameras(torch, oracle_mod):
         assert _depth_close(depths[r], depth.reshape(W, H).T, S_new, W, H) <= 0.02
 
 
-def _rank_main(rank, world, port, out_dir):
+def _rank_main(rank, world, port, out_dir, deterministic=False):
     import os
     import sys
     import torch
@@ -256,10 +256,10 @@ def _rank_main(rank, world, port, out_dir):
     H, W = 48, 64
     scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
     fp = get_forward_pass_factory("raynet")(bank, _gp(32, 192, (64, 64, 64)), "sample_in_bbox",
-                                            (H, W), 0)
+                                            (H, W), 0, deterministic=deterministic)
     depths = list(fp.forward_pass(scene, (0, 5, 1)))
-    np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), depth=np.stack(depths),
-             acc=fp.accumulator.cpu().numpy())
+    np.savez(os.path.join(out_dir, "%sw%d_r%d.npz" % ("d" if deterministic else "", world, rank)),
+             depth=np.stack(depths), acc=fp.accumulator.cpu().numpy())
     if world > 1:
         dist.destroy_process_group()
 
@@ -324,3 +324,43 @@ def test_row_layout_does_not_change_results(torch, filter_rays, monkeypatch):
         assert (np.abs(d - ref[0]) > 1e-4).mean() < 0.01
         tol = 2e-3 + 512 * 2.0 ** -24 * np.exp(np.minimum(np.abs(ref[2]), 17.0))
         assert np.all(np.abs(m - ref[2]) <= tol)
+
+
+def test_deterministic_mode_is_bit_identical_across_runs_and_ranks(torch, tmp_path):
+    """with 64-bit fixed-point sums (scatter, accumulator, all-reduce) the
+    accumulator and the depth maps are the SAME BITS run to run, and for 1 and 2 ranks; and
+    they agree with the default (float-atomic) mode to its usual tolerance."""
+    import socket
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    runs = []
+    for k in range(2):                                  # two single-rank runs
+        p = ctx.Process(target=_rank_main, args=(0, 1, 0, out, True))
+        p.start()
+        p.join(300)
+        assert p.exitcode == 0
+        d = np.load(out + "/dw1_r0.npz")
+        runs.append((d["acc"].copy(), d["depth"].copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    r0, r1 = np.load(out + "/dw2_r0.npz"), np.load(out + "/dw2_r1.npz")
+    assert np.array_equal(r0["acc"], r1["acc"]) and np.array_equal(r0["depth"], r1["depth"])
+    assert np.array_equal(r0["acc"], runs[0][0])        # 2 ranks == 1 rank, bit for bit
+    assert np.array_equal(r0["depth"], runs[0][1])
+    p = ctx.Process(target=_rank_main, args=(0, 1, 0, out, False))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    ref = np.load(out + "/w1_r0.npz")
+    assert np.abs(ref["acc"] - runs[0][0]).max() < 2e-3
+    assert (np.abs(ref["depth"] - runs[0][1]) > 1e-4).mean() < 0.01
