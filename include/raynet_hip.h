@@ -219,6 +219,10 @@ int rn_acc_copies(const rn_ctx *ctx);
  * RN_ROWS_LINEAR  -- consecutive rows run along an image column / row (ray-index order);
  * RN_ROWS_PATCHES -- every 256 consecutive rows are a compact pixel patch (e.g. 16x16). */
 typedef enum { RN_ROWS_LINEAR = 0, RN_ROWS_PATCHES = 1 } rn_row_layout;
+/* The scatter for RN_ROWS_PATCHES adapts its tile shape to the scene from what previous
+ * sweeps measured (LDS overflow counts); call this when the scene / cameras change so that
+ * the next sweeps start from the default again. */
+int rn_scatter_reset(rn_ctx *ctx);
 int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                       const int32_t *rvc, const float *acc_in, float *msgs, float *acc_part,
                       int32_t first_sweep, int32_t row_layout, void *stream);

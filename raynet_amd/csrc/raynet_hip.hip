@@ -1227,7 +1227,7 @@ struct rn_ctx {
     // LDS-box scatter: tile shape in use (0: 128 rays x 32 steps, 1: 256 x 16, 2: gave up, slab
     // scatter), {chunks, overflowed chunks} of the previous launches on the device and its
     // pinned host mirror
-    int box_level;
+    int box_level, box_level0;
     unsigned *box_stats, *box_stats_host;
     hipEvent_t ev0, ev1;
     // per-launch profiling (rn_prof_begin / rn_prof_end)
@@ -1493,7 +1493,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     const char *sm = getenv("RAYNET_HIP_SCATTER_MODE");
     ctx->scatter_mode = sm ? atoi(sm) : -1;
     const char *bs = getenv("RAYNET_HIP_BOX_LEVEL");      // A/B knob: start at this tile shape
-    ctx->box_level = bs ? max(0, min(2, atoi(bs))) : 0;
+    ctx->box_level = ctx->box_level0 = bs ? max(0, min(2, atoi(bs))) : 0;
     if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
         hipMalloc(&ctx->box_stats, 2 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc(&ctx->box_stats_host, 2 * sizeof(unsigned)) != hipSuccess ||
@@ -1764,6 +1764,13 @@ int rn_fused_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float 
 
 // ------------------------------------------------------ resident-scene path
 int rn_acc_copies(const rn_ctx *ctx) { return ctx ? 1 : 0; }
+
+int rn_scatter_reset(rn_ctx *ctx) {
+    if (!ctx) return RN_ERR_INVALID;
+    ctx->box_level = ctx->box_level0;
+    ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
+    return RN_OK;
+}
 
 int64_t rn_acc_size(const rn_ctx *ctx) { return ctx ? acc_floats(ctx) : 0; }
 

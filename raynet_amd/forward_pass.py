@@ -399,6 +399,8 @@ class RayNetForwardPass(ForwardPass):
         key = cam_host.tobytes()
         if self._cam_cache is None or self._cam_cache[0] != key:
             self._cam_cache = (key, ctx.dev(cam_host))
+            if hasattr(ctx, "scatter_reset"):
+                ctx.scatter_reset()      # new cameras: the scatter re-learns its tile shape
         cam_dev = self._cam_cache[1]
 
         # K1 prefix once per reference image; the per-ray columns of ALL images live in one

@@ -96,6 +96,9 @@ class HipContext(object):
     def acc_copies(self):
         return int(self.lib.rn_acc_copies(self._h))
 
+    def scatter_reset(self):
+        self._check(self.lib.rn_scatter_reset(self._h))
+
     # resident accumulators are 4x4x4-bricked (include/raynet_hip.h); the reference's
     # [gx][gy][gz] view is produced / consumed through these two
     def acc_size(self):
