@@ -929,7 +929,9 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             i0 += sx;
         }
     };
-    for (int s0 = 0; s0 < maxc; s0 += BOX_STEPS) {
+    // gridDim.y workgroups share a tile, taking every gridDim.y-th chunk: small launches (a
+    // rank of a multi-GPU run) still fill the chip
+    for (int s0 = blockIdx.y * BOX_STEPS; s0 < maxc; s0 += gridDim.y * BOX_STEPS) {
         const int st = s0 + col;
         // ---- this chunk's pairs into registers, and their bounding box
         float m[BOX_NB];
@@ -1032,7 +1034,9 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
         }
     }
     if (tid == 0 && overflow_stats)
-        atomicAdd(overflow_stats, (unsigned)((maxc + BOX_STEPS - 1) / BOX_STEPS));
+        atomicAdd(overflow_stats,
+                  (unsigned)((maxc + BOX_STEPS - 1) / BOX_STEPS + gridDim.y - 1 - blockIdx.y) /
+                      gridDim.y);
 }
 
 // deterministic scatter for rows the box kernel is not used on: every (ray, voxel) pair adds
@@ -1349,6 +1353,12 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
     launch_sweep_t<1, 1, 8, MAPMODE, PACKED>(ctx, a, st);
 }
 
+// workgroups per box-scatter tile (grid.y): enough of them for ~16 per CU
+inline int box_split(int n, int tile_rays) {
+    const int tiles = (n + tile_rays - 1) / tile_rays;
+    return max(1, min(4, 4096 / max(tiles, 1)));
+}
+
 // One BP sweep: k_bp (messages) + the accumulator scatter that fits the row layout.
 template <bool PACKED, bool CLIP_IN>
 int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
@@ -1388,17 +1398,17 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
         level = ctx->box_level;
     }
     if (level == 0 && !fixed)
-        hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32>), dim3((n + 127) / 128), dim3(BLOCK), 0,
+        hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32>), dim3((n + 127) / 128, box_split(n, 128)), dim3(BLOCK), 0,
                            st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
     else if (level == 0)
-        hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32, true>), dim3((n + 127) / 128),
+        hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32, true>), dim3((n + 127) / 128, box_split(n, 128)),
                            dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
                            ctx->box_stats);
     else if (level == 1 && !fixed)
-        hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16>), dim3((n + 255) / 256), dim3(BLOCK), 0,
+        hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16>), dim3((n + 255) / 256, box_split(n, 256)), dim3(BLOCK), 0,
                            st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
     else if (level == 1)
-        hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16, true>), dim3((n + 255) / 256),
+        hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16, true>), dim3((n + 255) / 256, box_split(n, 256)),
                            dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
                            ctx->box_stats);
     else if (fixed)
