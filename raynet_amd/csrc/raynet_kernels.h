@@ -215,6 +215,9 @@ __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureView
 #ifndef RN_SWEEP_V4
 #define RN_SWEEP_V4 1
 #endif
+#ifndef RN_SWEEP_UNROLL2_MAX_VIEWS
+#define RN_SWEEP_UNROLL2_MAX_VIEWS 6
+#endif
 template <int NV, int LPS>
 __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &fv,
                                            const float *const *__restrict__ tbl,
@@ -239,7 +242,8 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             for (int v = 0; v < NV; v++) offb[v] = feature_offset(p, P + 12 * v, point) * 4;
         }
         float mine = 0.0f;
-#pragma unroll 2
+        // two rounds of loads in flight while the view count leaves registers for it
+#pragma clang loop unroll_count(NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? 2 : 1)
         for (int it = 0; it < LPS; it++) {
             const int src = it * SPL + sub;   // plane (within the chunk) this lane helps with
             // lane's 16*V4 bytes of every view's vector, as channel pairs: the packed FMAs below
