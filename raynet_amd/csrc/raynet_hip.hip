@@ -808,14 +808,11 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
 // registers (BOX_NB per thread, one round trip), the box is the exact bounding box of those
 // voxels -- no assumption on the lists -- and a chunk whose box exceeds the LDS budget (rows
 // that are not patch-ordered) goes straight to the global atomics: always correct.
-#ifndef RN_BOX_CAP
-#define RN_BOX_CAP 4096
-#endif
-constexpr int BOX_CAP = RN_BOX_CAP;      // voxels (doubles of LDS) per chunk
-// Tile shapes (rays x steps): 128 x 32 reads 128 B of every row per round trip (whole cache
-// lines) and is the default; scenes whose bundles are too wide for the LDS budget at 32
-// steps (fine grids, oblique views) switch to 256 x 16 -- the kernel counts the chunks that
-// overflowed and the launcher looks at the previous launches' count (rn_ctx::box_*).
+// Tile shapes (rays x steps) and LDS capacity (voxels): 128 x 32 reads 128 B of every row per
+// round trip (whole cache lines) and is the default with 4096 voxels (32 KB, 5 workgroups per
+// CU); scenes whose bundles do not fit (fine grids, oblique views) first get 6144 voxels, then
+// 256 x 16 tiles -- the kernel counts the chunks that overflowed and the launcher looks at
+// the previous launches' count (rn_ctx::box_*).
 __device__ __forceinline__ int wave_reduce_max(int x) { return lane63i(wave_scan_max(x)); }
 __device__ __forceinline__ int wave_reduce_min(int x) { return ~wave_reduce_max(~x); }
 // What the scatter sums in.  Default: doubles in LDS, float atomics on the accumulator (the
@@ -860,11 +857,13 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                                        const int32_t *__restrict__ vox,
                                                        const int32_t *__restrict__ rvc,
                                                        void *acc_out_raw,
-                                                       unsigned *overflow_stats) {
+                                                       unsigned *overflow_stats, int BOX_CAP) {
     typedef AccSum<FIXED> Sum;
     typename Sum::acc_t *acc_out = static_cast<typename Sum::acc_t *>(acc_out_raw);
     constexpr int BOX_NB = BOX_RAYS * BOX_STEPS / BLOCK;     // pairs per thread and chunk
-    __shared__ typename Sum::box_t box[BOX_CAP];
+    // BOX_CAP voxels (8 bytes each) of dynamic LDS: the launcher trades capacity for occupancy
+    extern __shared__ __attribute__((aligned(16))) unsigned long long box_raw[];
+    typename Sum::box_t *box = reinterpret_cast<typename Sum::box_t *>(box_raw);
     __shared__ int red[2][6 * WAVES_PER_BLOCK];
     __shared__ int red_cnt[WAVES_PER_BLOCK];
     __shared__ int cnts[BOX_RAYS];
@@ -1228,10 +1227,10 @@ struct rn_ctx {
     float *axes;          // device, gx+gy+gz
     bool have_axes;
     int scatter_mode;     // A/B knob RAYNET_HIP_SCATTER_MODE: -1 by row layout (default), 0 slab, 2 LDS box
-    // LDS-box scatter: tile shape in use (0: 128 rays x 32 steps, 1: 256 x 16, 2: gave up, slab
-    // scatter), {chunks, overflowed chunks} of the previous launches on the device and its
-    // pinned host mirror
+    // LDS-box scatter: level in use (launch_bp), {chunks, overflowed chunks} of the previous
+    // launches on the device and its pinned host mirror
     int box_level, box_level0;
+    bool box_pin;         // RAYNET_HIP_BOX_PIN: stay at the starting level (A/B runs)
     unsigned *box_stats, *box_stats_host;
     hipEvent_t ev0, ev1;
     // per-launch profiling (rn_prof_begin / rn_prof_end)
@@ -1382,46 +1381,46 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     ProfScope prof(ctx, RN_K_SCATTER, n, st);
     // Patch-ordered rows start with the LDS-box scatter on 128-ray x 32-step tiles.  The
     // kernel counts the chunks whose bounding box did not fit its LDS budget; the count of
-    // the previous launches is copied out asynchronously (it may lag a launch) and when more
-    // too many overflowed the tile shape steps down: 256 x 16, then -- pixel spacing above
-    // the voxel size, nothing to sum per voxel anyway -- the slab-ordered scatter.
-    int level = ctx->scatter_mode == 0 ? 2 : (ctx->scatter_mode == 2 || patch_rows) ? 0 : 2;
+    // the previous launches is copied out asynchronously (it may lag a launch) and when too
+    // many overflowed the launcher steps down: more LDS, then narrower chunks, then -- pixel
+    // spacing above the voxel size, nothing to sum per voxel anyway -- the slab scatter.
+    // levels: 0 = 128 x 32 tiles with a 4096-voxel box (32 KB), 1 = 256 x 16 tiles with 6144
+    // voxels (48 KB; measured best of 4096..8192 on the 256^3 grid of config 4), 2 = slab
+    // scatter.  0 -> 1 above 2 % overflowed chunks, 1 -> 2 only above 25 % (the box kernel's
+    // quarter-chunk fallback still beats the slab scatter below that).
+    constexpr int LAST = 2;
+    int level = ctx->scatter_mode == 0 ? LAST : (ctx->scatter_mode == 2 || patch_rows) ? 0 : LAST;
     if (level == 0) {
-        // 128 x 32 -> 256 x 16 above 2 % overflow; 256 x 16 -> slab only above 25 % (its
-        // quarter-chunk fallback still beats the slab scatter on patch-ordered rows below that)
-        const unsigned per = ctx->box_level == 0 ? 50u : 4u;
-        if (ctx->box_level < 2 && ctx->box_stats_host[0] > 0 &&
+        const unsigned per = ctx->box_level < LAST - 1 ? 50u : 4u;
+        if (!ctx->box_pin && ctx->box_level < LAST && ctx->box_stats_host[0] > 0 &&
             ctx->box_stats_host[1] * per > ctx->box_stats_host[0]) {
             ctx->box_level++;
             ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
         }
         level = ctx->box_level;
     }
-    if (level == 0 && !fixed)
-        hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32>), dim3((n + 127) / 128, box_split(n, 128)), dim3(BLOCK), 0,
-                           st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
-    else if (level == 0)
-        hipLaunchKernelGGL((k_scatter_box<PACKED, 128, 32, true>), dim3((n + 127) / 128, box_split(n, 128)),
-                           dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
-                           ctx->box_stats);
-    else if (level == 1 && !fixed)
-        hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16>), dim3((n + 255) / 256, box_split(n, 256)), dim3(BLOCK), 0,
-                           st, ctx->p, n, msgs_out, vox, rvc, acc_out, ctx->box_stats);
-    else if (level == 1)
-        hipLaunchKernelGGL((k_scatter_box<PACKED, 256, 16, true>), dim3((n + 255) / 256, box_split(n, 256)),
-                           dim3(BLOCK), 0, st, ctx->p, n, msgs_out, vox, rvc, acc_out,
-                           ctx->box_stats);
-    else if (fixed)
+#define RN_BOX(RAYS, STEPS, FIXED_, CAP)                                                          \
+    hipLaunchKernelGGL((k_scatter_box<PACKED, RAYS, STEPS, FIXED_>),                              \
+                       dim3((n + RAYS - 1) / RAYS, box_split(n, RAYS)), dim3(BLOCK),              \
+                       (CAP) * sizeof(double), st, ctx->p, n, msgs_out, vox, rvc, acc_out,        \
+                       ctx->box_stats, CAP)
+    if (level == 0) {
+        if (fixed) RN_BOX(128, 32, true, 4096); else RN_BOX(128, 32, false, 4096);
+    } else if (level == 1) {
+        if (fixed) RN_BOX(256, 16, true, 6144); else RN_BOX(256, 16, false, 6144);
+    } else if (fixed) {
         hipLaunchKernelGGL((k_scatter_direct_fixed<PACKED>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st,
                            ctx->p, n, msgs_out, vox, rvc,
                            static_cast<unsigned long long *>(acc_out));
-    else
+    } else {
         hipLaunchKernelGGL((k_scatter_slab<PACKED>),
                            dim3(((n + WAVE - 1) / WAVE) *
                                 ((ctx->p.M + SLAB_STEPS - 1) / SLAB_STEPS)),
                            dim3(WAVE), 0, st, ctx->p, n, msgs_out, vox, rvc,
                            static_cast<float *>(acc_out));
-    if (level < 2) {
+    }
+#undef RN_BOX
+    if (level < LAST) {
         (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
                              hipMemcpyDeviceToHost, st);
         (void)hipMemsetAsync(ctx->box_stats, 0, 2 * sizeof(unsigned), st);
@@ -1504,6 +1503,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     ctx->scatter_mode = sm ? atoi(sm) : -1;
     const char *bs = getenv("RAYNET_HIP_BOX_LEVEL");      // A/B knob: start at this tile shape
     ctx->box_level = ctx->box_level0 = bs ? max(0, min(2, atoi(bs))) : 0;
+    ctx->box_pin = getenv("RAYNET_HIP_BOX_PIN") != nullptr;
     if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
         hipMalloc(&ctx->box_stats, 2 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc(&ctx->box_stats_host, 2 * sizeof(unsigned)) != hipSuccess ||
