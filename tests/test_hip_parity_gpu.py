@@ -804,3 +804,57 @@ def test_maximum_sizes_m1024(torch, oracle_mod):
         args.update(kw)
         with pytest.raises(_lib.RaynetHipError):
             HipContext(**args)
+
+
+def test_scatter_levels_agree_and_fixed_point_is_level_independent(torch, oracle_mod, monkeypatch):
+    """The three scatter levels the launcher can choose (128x32 box, 256x16 box, slab /
+    direct) produce the same accumulator -- to float-atomic tolerance in the default mode, and
+    BIT-IDENTICAL in the fixed-point mode, whose integer sums do not depend on how the pairs
+    are grouped."""
+    from raynet_amd.forward_pass import tile_order
+    from raynet_amd.hip_implementations.context import HipContext
+    H, W, M, D, grid = 64, 48, 96, 16, (48, 48, 48)
+    bbox = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    o = oracle_mod.Oracle(M=M, D=D, N=2, F=4, H=H, W=W, padding=3, bbox=bbox, grid_shape=grid)
+    vg = oracle_mod.voxel_grid_centers(bbox, grid)
+    n = H * W
+    idx = tile_order(torch.arange(n, dtype=torch.int32), H, W, 16, 16)
+    x, y = (idx // H).numpy().astype(np.float32), (idx % H).numpy().astype(np.float32)
+    cam = np.array([0.1, -0.2, -3.0], np.float32)
+    d = np.stack([(x / W - 0.5) * 1.8, (y / H - 0.5) * 1.8, np.ones(n, np.float32)], 1) - cam
+    starts = (cam + d * (2.0 / d[:, 2:3])).astype(np.float32)
+    ends = (cam + d * (4.0 / d[:, 2:3])).astype(np.float32)
+    rvi, rvc = o.traversal(starts, ends)
+    rng = np.random.default_rng(4)
+    Sr = rng.random((n, M)).astype(np.float32) + 0.01
+    Sr *= np.arange(M)[None, :] < rvc[:, None]
+    Sr /= np.maximum(Sr.sum(1, keepdims=True), 1e-30)
+    packed = torch.from_numpy(((rvi[..., 0] << 20) | (rvi[..., 1] << 10) | rvi[..., 2])
+                              .astype(np.int32)).cuda()
+    Sr_d, rvc_d = torch.from_numpy(Sr).cuda(), torch.from_numpy(rvc).cuda()
+    monkeypatch.setenv("RAYNET_HIP_BOX_PIN", "1")
+    floats, fixeds = [], []
+    for level in (0, 1, 2):
+        monkeypatch.setenv("RAYNET_HIP_BOX_LEVEL", str(level))
+        ctx = HipContext(M, D, 2, 4, H, W, 3, bbox, grid)       # env is read at rn_create
+        ctx.set_voxel_grid(torch.from_numpy(vg).cuda())
+        G = ctx.acc_size()
+        acc_in = torch.full((G,), -2.9, device="cuda")
+        part = torch.zeros((1, G), device="cuda")
+        msgs = torch.zeros((n, M), device="cuda")
+        ctx.scene_bp_sweep(Sr_d, packed, rvc_d, acc_in, msgs, part, first_sweep=True,
+                           patch_rows=True)
+        floats.append(ctx.acc_to_grid(part[0]).cpu().numpy())
+        part64 = torch.zeros((G,), dtype=torch.int64, device="cuda")
+        ctx.scene_bp_sweep_fixed(Sr_d, packed, rvc_d, acc_in, msgs, part64, first_sweep=True,
+                                 patch_rows=True)
+        out = torch.empty((G,), device="cuda")
+        ctx.acc_combine_fixed(part64, 0.0, out)
+        assert int(part64.abs().max()) == 0                      # partial zeroed by the combine
+        fixeds.append(ctx.acc_to_grid(out).cpu().numpy())
+    scale = np.abs(floats[0]).max()
+    assert scale > 1.0
+    for level in (1, 2):
+        assert np.abs(floats[level] - floats[0]).max() < 2e-5 * scale
+        assert np.array_equal(fixeds[level], fixeds[0])
+    assert np.abs(fixeds[0] - floats[0]).max() < 2e-5 * scale
