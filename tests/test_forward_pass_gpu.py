@@ -364,3 +364,27 @@ def test_deterministic_mode_is_bit_identical_across_runs_and_ranks(torch, tmp_pa
     ref = np.load(out + "/w1_r0.npz")
     assert np.abs(ref["acc"] - runs[0][0]).max() < 2e-3
     assert (np.abs(ref["depth"] - runs[0][1]) > 1e-4).mean() < 0.01
+
+
+@pytest.mark.parametrize("H,W,V,nb,tile", [(37, 53, 5, 4, (16, 16)), (37, 53, 3, 2, None),
+                                            (50, 70, 4, 3, (16, 16)), (16, 16, 2, 1, (16, 16)),
+                                            (33, 17, 5, 4, (8, 32))])
+def test_ragged_image_sizes_view_counts_and_tiles(torch, H, W, V, nb, tile):
+    """Image sizes that are no multiple of the patch, 2..5 views, odd neighbour counts, other
+    patch shapes: finite maps of the right shape, and the fixed-point mode agrees with the
+    float-atomic one."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=V, focal=1.5 * H)
+    gp = _gp(16, 96, (32, 32, 32), neighbors=nb)
+    outs = []
+    for det in (False, True):
+        fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0,
+                                                deterministic=det)
+        fp.ray_tile = tile
+        d = list(fp.forward_pass(scene, (0, V, 1)))
+        assert len(d) == V and d[0].shape == (H, W) and np.isfinite(np.stack(d)).all()
+        assert (np.stack(d) > 0).all()
+        outs.append((np.stack(d), fp.accumulator.cpu().numpy()))
+    assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-3
+    assert (np.abs(outs[0][0] - outs[1][0]) > 1e-4).mean() < 0.01
