@@ -212,13 +212,19 @@ int64_t rn_acc_size(const rn_ctx *ctx);
 int rn_acc_to_grid(rn_ctx *ctx, const float *acc, float *grid_out, void *stream);
 int rn_acc_from_grid(rn_ctx *ctx, const float *grid, float *acc_out, void *stream);
 int rn_acc_copies(const rn_ctx *ctx);
-/* first_sweep != 0: the messages are taken as zero and `msgs` is only written, so it
- * needs no zero-fill (the reference zero-fills for iteration 0, forward_pass.py:613-615).
+/* first_sweep is a set of rn_sweep_flags:
+ * RN_SWEEP_ZERO_MSGS   the messages are taken as zero and `msgs` is only written, so it needs
+ *                      no zero-fill (the reference zero-fills for iteration 0,
+ *                      forward_pass.py:613-615);
+ * RN_SWEEP_UNIFORM_ACC every voxel of acc_in holds acc_in[0] (iteration 0 starts from the
+ *                      prior everywhere, forward_pass.py:533-538): only that element is read,
+ *                      nothing is gathered.
  * row_layout says how consecutive rows relate in the image, which only selects the
  * accumulator-scatter kernel (any value is correct for any input, it is a speed hint):
  * RN_ROWS_LINEAR  -- consecutive rows run along an image column / row (ray-index order);
  * RN_ROWS_PATCHES -- every 256 consecutive rows are a compact pixel patch (e.g. 16x16). */
 typedef enum { RN_ROWS_LINEAR = 0, RN_ROWS_PATCHES = 1 } rn_row_layout;
+typedef enum { RN_SWEEP_ZERO_MSGS = 1, RN_SWEEP_UNIFORM_ACC = 2 } rn_sweep_flags;
 /* The scatter for RN_ROWS_PATCHES adapts its tile shape to the scene from what previous
  * sweeps measured (LDS overflow counts); call this when the scene / cameras change so that
  * the next sweeps start from the default again. */

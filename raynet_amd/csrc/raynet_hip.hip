@@ -495,17 +495,23 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
                                        const float *__restrict__ S,
                                        const int32_t *__restrict__ vox,
                                        const float *__restrict__ acc_in, const float *msgs_in,
-                                       float *msgs_out) {
+                                       float *msgs_out, bool uniform_acc) {
     RayRows<NB> cur;
     load_rows<NB, PACKED>(p, cur, S, vox, msgs_in, r, count, lane);
-    // accumulator gather (depends on the voxel rows)
+    // accumulator gather (depends on the voxel rows).  uniform_acc: every voxel holds
+    // acc_in[0] (the first iteration starts from the prior everywhere) -- nothing to gather,
+    // and with zero messages on top the occupancy is one constant for the whole sweep.
     float av[NB];
+    const float a0 = uniform_acc ? acc_in[0] : 0.0f;
 #pragma unroll
     for (int ch = 0; ch < NB; ch++) {
         const int i = ch * WAVE + lane;
-        av[ch] = 0.0f;
-        if (ch * WAVE < count && i < count) av[ch] = gather_acc(acc_in, lin_of<PACKED>(p, cur.pk[ch]));
+        av[ch] = a0;
+        if (!uniform_acc && ch * WAVE < count && i < count)
+            av[ch] = gather_acc(acc_in, lin_of<PACKED>(p, cur.pk[ch]));
     }
+    const bool const_o = uniform_acc && msgs_in == nullptr;
+    const float o_const = occupancy_to_ray(a0, 0.0f);
     float *mout_row = msgs_out + (size_t)r * p.M;
     clip_renorm_rows<NB, CLIP_IN>(cur.sv, count, lane);
 
@@ -518,7 +524,9 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
         if (ch * WAVE < count) {
             const int i = ch * WAVE + lane;
             const bool valid = i < count;
-            const float o = valid ? occupancy_to_ray(av[ch], cur.mv[ch]) : 0.0f;
+            float o = o_const;
+            if (!const_o) o = occupancy_to_ray(av[ch], cur.mv[ch]);
+            if (!valid) o = 0.0f;
             const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
             const float T = carryT * wave_shift1(incl, 1.0f);
             carryT = carryT * lane63(incl);
@@ -572,7 +580,8 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
                                               const int32_t *__restrict__ vox,
                                               const int32_t *__restrict__ rvc,
                                               const float *__restrict__ acc_in,
-                                              const float *msgs_in, float *msgs_out) {
+                                              const float *msgs_in, float *msgs_out,
+                                              int uniform_acc) {
     int lane;
     const int r = ray_of_wave(n, lane);
     if (r < 0) return;
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__re
     if (count <= 1) return;   // mrf_np.py:300: such rays send nothing
     const int nch = (count + WAVE - 1) / WAVE;
 #define RN_BP_BODY(NB) \
-    bp_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc_in, msgs_in, msgs_out)
+    bp_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc_in, msgs_in, msgs_out, uniform_acc != 0)
     RN_DISPATCH_CHUNKS(NCH, nch, RN_BP_BODY);
 #undef RN_BP_BODY
 }
@@ -1362,13 +1371,14 @@ inline int box_split(int n, int tile_rays) {
 template <bool PACKED, bool CLIP_IN>
 int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
               const float *acc_in, const float *msgs_in, void *acc_out, float *msgs_out,
-              hipStream_t st, bool patch_rows = false, bool fixed = false) {
+              hipStream_t st, bool patch_rows = false, bool fixed = false,
+              bool uniform_acc = false) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     {
         ProfScope prof(ctx, RN_K_BP, n, st);
 #define RN_BP(NCH_)                                                                            \
     hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
-                       ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, msgs_out)
+                       ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, msgs_out, uniform_acc ? 1 : 0)
         if (nch <= 2) RN_BP(2);
         else if (nch <= 4) RN_BP(4);
         else if (nch <= 6) RN_BP(6);
@@ -1874,8 +1884,10 @@ int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vo
     if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc_in || !msgs || !acc_part)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
     if (n == 0) return RN_OK;
-    return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, first_sweep ? nullptr : msgs,
-                                  acc_part, msgs, S(stream), row_layout == RN_ROWS_PATCHES);
+    return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in,
+                                  (first_sweep & RN_SWEEP_ZERO_MSGS) ? nullptr : msgs, acc_part,
+                                  msgs, S(stream), row_layout == RN_ROWS_PATCHES, false,
+                                  (first_sweep & RN_SWEEP_UNIFORM_ACC) != 0);
 }
 
 int rn_scene_bp_sweep_fixed(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
@@ -1885,9 +1897,10 @@ int rn_scene_bp_sweep_fixed(rn_ctx *ctx, int32_t n, const float *Sr, const int32
     if (ctx && n == 0) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n < 0 || !Sr || !vox || !rvc || !acc_in || !msgs || !acc_part_fixed)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
-    return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in, first_sweep ? nullptr : msgs,
+    return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in,
+                                  (first_sweep & RN_SWEEP_ZERO_MSGS) ? nullptr : msgs,
                                   acc_part_fixed, msgs, S(stream), row_layout == RN_ROWS_PATCHES,
-                                  true);
+                                  true, (first_sweep & RN_SWEEP_UNIFORM_ACC) != 0);
 }
 
 int rn_acc_combine_fixed(rn_ctx *ctx, int64_t *acc_part_fixed, float prior, float *acc_out,

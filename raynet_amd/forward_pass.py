@@ -502,7 +502,8 @@ class RayNetForwardPass(ForwardPass):
             sweep = ctx.scene_bp_sweep_fixed if fixed else ctx.scene_bp_sweep
             for i in range(0, n_all, B_all):
                 sweep(Sr_all[i:i + B_all], vox_all[i:i + B_all], rvc_all[i:i + B_all], acc_in,
-                      msgs_all[i:i + B_all], acc_part, first_sweep=first, patch_rows=patch_rows)
+                      msgs_all[i:i + B_all], acc_part, first_sweep=first, patch_rows=patch_rows,
+                      uniform_acc=it == 0)      # iteration 0: the prior everywhere
             # swap + prior refill of forward_pass.py:676-678; across ranks the prior is
             # added once, after the sum
             if fixed:

@@ -292,18 +292,19 @@ class HipContext(object):
             _ptr(self._segments(int(n_images) * int(rows_per_image))), _stream()))
 
     def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False,
-                       patch_rows=False):
+                       patch_rows=False, uniform_acc=False):
         self._check(self.lib.rn_scene_bp_sweep(self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc),
                                                _ptr(acc_in), _ptr(msgs), _ptr(acc_part),
-                                               1 if first_sweep else 0, 1 if patch_rows else 0,
-                                               _stream()))
+                                               (1 if first_sweep else 0) | (2 if uniform_acc else 0),
+                                               1 if patch_rows else 0, _stream()))
 
     def scene_bp_sweep_fixed(self, Sr, vox, rvc, acc_in, msgs, acc_part_fixed, first_sweep=False,
-                             patch_rows=False):
+                             patch_rows=False, uniform_acc=False):
         assert acc_part_fixed.dtype == torch.int64
         self._check(self.lib.rn_scene_bp_sweep_fixed(
             self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc), _ptr(acc_in), _ptr(msgs),
-            _ptr(acc_part_fixed), 1 if first_sweep else 0, 1 if patch_rows else 0, _stream()))
+            _ptr(acc_part_fixed), (1 if first_sweep else 0) | (2 if uniform_acc else 0),
+            1 if patch_rows else 0, _stream()))
 
     def acc_combine_fixed(self, acc_part_fixed, prior, acc_out):
         assert acc_part_fixed.dtype == torch.int64

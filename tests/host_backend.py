@@ -56,7 +56,7 @@ class OracleBackend(object):
         Sr.numpy()[...] = Sv        # clipped + renormalised inside the oracle's BP / depth calls
 
     def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False,
-                       patch_rows=False):
+                       patch_rows=False, uniform_acc=False):
         if first_sweep:
             msgs.zero_()
         m = np.ascontiguousarray(msgs.numpy())
