@@ -389,7 +389,9 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
             sum += v;
         }
         sum = __builtin_amdgcn_rcpf(wave_sum(sum));
-        for (int i = lane; i < count; i += WAVE) out[i] = vals[i] * sum;
+        // streamed out, read again only by later kernels: keep it out of the L2 the feature
+        // gathers live in
+        for (int i = lane; i < count; i += WAVE) __builtin_nontemporal_store(vals[i] * sum, out + i);
     }
 }
 
