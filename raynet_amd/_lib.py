@@ -31,6 +31,7 @@ class RaynetHipError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "raynet_hip.hip"), os.path.join(CSRC, "raynet_kernels.h"),
+            os.path.join(CSRC, "raynet_prepare.inl"), os.path.join(CSRC, "raynet_mrf.inl"),
             os.path.join(CSRC, "raynet_train.inl"), os.path.join(CSRC, "raynet_eval.inl"), HEADER]
     if not force and os.path.exists(LIB_PATH) and \
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):

@@ -1,0 +1,313 @@
+// raynet_prepare.inl -- the per-ray prefix of the path: ray sampling (K8), voxel traversal
+// (K5) and the plane sweep + planes->voxels mapping (K6 / K7 / K9-K12, the K1 prefix).
+// Included by raynet_hip.hip inside its anonymous namespace.
+
+// ------------------------------------------------------------ K8 / sampling
+__global__ void k_sample_rays(Params p, int n, const int32_t *__restrict__ ray_idxs,
+                              const float *__restrict__ P_inv, const float *__restrict__ cc,
+                              float *starts, float *ends) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float s[3], e[3];
+    sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+    for (int i = 0; i < 3; i++) {
+        starts[3 * r + i] = s[i];
+        ends[3 * r + i] = e[i];
+    }
+}
+// sampling_schemes.cu:92-122: one wave per ray, lanes over planes
+__global__ void k_sample_points(Params p, int n, const int32_t *__restrict__ ray_idxs,
+                                const float *__restrict__ P_inv, const float *__restrict__ cc,
+                                float *points) {
+    int lane;
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    float s[3], e[3];
+    sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+    float4 *row = reinterpret_cast<float4 *>(points) + (size_t)r * p.D;
+    for (int k = lane; k < p.D; k += WAVE) {
+        float pt[3];
+        plane_point(s, e, k, p.D, pt);
+        row[k] = make_float4(pt[0], pt[1], pt[2], 1.0f);
+    }
+}
+
+// ------------------------------------------------------------ K5 traversal
+// One thread per ray (the DDA is a chain of sequential fp32 additions, bit-exactness
+// forbids re-associating it).  Source of the segment: explicit starts/ends, or the
+// camera (sample_in_bbox), as in the fused kernels.
+// A thread writing its own row step by step produces one partial-line write per voxel
+// (4x write amplification measured).  Each 64-thread block therefore collects
+// [64 rays][TRAV_TILE steps] in LDS and writes finished tiles as coalesced row segments.
+constexpr int TRAV_TILE = 32;
+template <bool PACKED>
+__global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
+                                                   const int32_t *__restrict__ ray_idxs,
+                                                   const float *__restrict__ P_inv,
+                                                   const float *__restrict__ cc,
+                                                   const float *__restrict__ starts,
+                                                   const float *__restrict__ ends, int32_t *vox,
+                                                   int32_t *rvc, int cam_stride,
+                                                   int64_t rows_per_image, float *seg_out) {
+    __shared__ int32_t tile[WAVE * (TRAV_TILE + 1)];
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.x * WAVE;
+    if (rows_per_image > 0) {       // blockIdx.y = reference image of a scene-wide launch
+        const int g = blockIdx.y;
+        P_inv += (size_t)g * cam_stride;
+        cc += (size_t)g * cam_stride;
+        vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
+        rvc += (size_t)g * rows_per_image;
+        if (seg_out) seg_out += (size_t)g * rows_per_image * 8;
+    }
+    const int r = r0 + lane;
+    const bool live = r < n;
+    float s[3] = {0.f, 0.f, 0.f}, e[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        if (ray_idxs) {
+            sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+        } else {
+            for (int i = 0; i < 3; i++) {
+                s[i] = starts[3 * r + i];
+                e[i] = ends[3 * r + i];
+            }
+        }
+        // the plane sweep (one wavefront per ray) reads the segment back instead of repeating
+        // the double-precision back-projection 64 lanes wide
+        if (seg_out) {
+            reinterpret_cast<float4 *>(seg_out)[2 * (size_t)r] = make_float4(s[0], s[1], s[2], 0.f);
+            reinterpret_cast<float4 *>(seg_out)[2 * (size_t)r + 1] = make_float4(e[0], e[1], e[2], 0.f);
+        }
+    }
+    // ---- DDA set-up (ray_tracing.pyx:99-161), identical arithmetic to rn::dda
+    const float EPS = 1e-2f;
+    const int g[3] = {p.gx, p.gy, p.gz};
+    float ss[3], ee[3], bin[3], ray[3], tm[3], td[3];
+    int step[3], cur[3], last[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ss[i] = s[i] - p.bbox[i];
+        ee[i] = e[i] - p.bbox[i];
+        bin[i] = (p.bbox[3 + i] - p.bbox[i]) / g[i];
+        ray[i] = ee[i] - ss[i];
+        step[i] = ray[i] >= 0 ? 1 : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ss[i] += step[i] * bin[i] * EPS;
+        ee[i] -= step[i] * bin[i] * EPS;
+        cur[i] = (int)floorf(ss[i] / bin[i]);
+        last[i] = (int)floorf(ee[i] / bin[i]);
+    }
+    bool active = live && !(cur[0] < 0 || cur[0] >= g[0] || cur[1] < 0 || cur[1] >= g[1] ||
+                            cur[2] < 0 || cur[2] >= g[2]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        tm[i] = FLT_MAX;
+        if (ray[i] != 0) {
+            const float c = cur[i] * bin[i];
+            float b;
+            if (step[i] < 0 && c < ss[i])
+                b = c;
+            else
+                b = c + step[i] * bin[i];
+            tm[i] = (b - ss[i]) / ray[i];
+        }
+        td[i] = ray[i] != 0 ? step[i] * bin[i] / ray[i] : FLT_MAX;
+    }
+    int cx = cur[0], cy = cur[1], cz = cur[2];
+    float tx = tm[0], ty = tm[1], tz = tm[2];
+    int count = 0;           // voxels emitted so far by this ray
+    // `active` = this ray still has a voxel (cx,cy,cz) to emit at index `count`
+    for (int base = 0; base < p.M; base += TRAV_TILE) {
+        if (__ballot(active) == 0) break;
+        for (int k = 0; k < TRAV_TILE && base + k < p.M; k++) {
+            if (active) {
+                tile[lane * (TRAV_TILE + 1) + k] = pack_voxel(cx, cy, cz);
+                count++;
+                // advance (ray_tracing.pyx:166-197)
+                if ((cx == last[0] && cy == last[1] && cz == last[2]) || count >= p.M) {
+                    active = false;
+                } else if (tx < ty) {
+                    if (tx < tz) {
+                        cx += step[0];
+                        if (cx < 0 || cx >= g[0]) active = false;
+                        tx += td[0];
+                    } else {
+                        cz += step[2];
+                        if (cz < 0 || cz >= g[2]) active = false;
+                        tz += td[2];
+                    }
+                } else {
+                    if (ty < tz) {
+                        cy += step[1];
+                        if (cy < 0 || cy >= g[1]) active = false;
+                        ty += td[1];
+                    } else {
+                        cz += step[2];
+                        if (cz < 0 || cz >= g[2]) active = false;
+                        tz += td[2];
+                    }
+                }
+            }
+        }
+        wave_sync();
+        // flush: TRAV_TILE consecutive steps of one ray are one contiguous segment
+        constexpr int RPI = WAVE / TRAV_TILE;      // rows per instruction
+#pragma unroll 4
+        for (int j = 0; j < WAVE; j += RPI) {
+            const int row = j + lane / TRAV_TILE;
+            const int col = lane % TRAV_TILE;
+            const int c = __shfl(count, row);
+            if (r0 + row < n && base + col < c) {
+                const int v = tile[row * (TRAV_TILE + 1) + col];
+                const size_t off = (size_t)(r0 + row) * p.M + base + col;
+                if (PACKED) {
+                    vox[off] = v;
+                } else {
+                    vox[3 * off] = v >> 20;
+                    vox[3 * off + 1] = (v >> 10) & 1023;
+                    vox[3 * off + 2] = v & 1023;
+                }
+            }
+        }
+        wave_sync();
+    }
+    if (live) rvc[r] = count;   // written even when 0
+}
+
+// ---------------------------------------- plane sweep (+ mapping) per wavefront
+// SIM      0: read the plane column from S_in [n][D] (K6)
+//          1: generic sweep (any N, F), 2: cooperative sweep (F = 4*LPS, N = NV)
+// MAPMODE  0: write the plane column to S_planes [n][D]            (K7 / K9 / K10)
+//          1: map to voxels, write S_voxel = vals / sum             (K6 / K11 / K1 / K2 prefix)
+//          2: as 1, then clip_and_renorm (mrf_bp.cu:103-111) -> Sr  (resident-scene path)
+// Dynamic LDS: [axes gx+gy+gz][per wave: D plane column][per wave: M values]
+template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
+__global__ __launch_bounds__(BLOCK) void k_sweep_map(
+    Params p, int n, const int32_t *__restrict__ ray_idxs, FeatureViews fv,
+    const float *__restrict__ P, const float *__restrict__ P_inv, const float *__restrict__ cc,
+    const float *__restrict__ starts, const float *__restrict__ ends,
+    const float *__restrict__ S_in, const float *__restrict__ axes_g,
+    const int32_t *__restrict__ vox, const int32_t *__restrict__ rvc, float *S_planes,
+    float *S_voxel, float *depth_from_planes, float *points,
+    const int32_t *__restrict__ order, const float *const *__restrict__ fv_table, int cam_stride,
+    int64_t rows_per_image, const float *__restrict__ seg) {
+    if (rows_per_image > 0) {       // blockIdx.y = reference image of a scene-wide launch
+        const int g = blockIdx.y;
+        P += (size_t)g * cam_stride;
+        P_inv += (size_t)g * cam_stride;
+        cc += (size_t)g * cam_stride;
+        fv_table += (size_t)g * p.N;
+        vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
+        rvc += (size_t)g * rows_per_image;
+        S_voxel += (size_t)g * rows_per_image * p.M;
+        if (seg) seg += (size_t)g * rows_per_image * 8;
+    }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int naxes = p.gx + p.gy + p.gz;
+    float *axes = smem;
+    const int wid = threadIdx.x >> 6;
+    float *Sl = smem + ((naxes + 3) & ~3) + wid * (p.D + p.M);
+    float *vals = Sl + p.D;
+    if (MAPMODE != 0) {
+        for (int i = threadIdx.x; i < naxes; i += BLOCK) axes[i] = axes_g[i];
+        __syncthreads();
+    }
+    int lane;
+    int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    if (order) r = uniform(order[r]);      // schedule only: which ray this wavefront takes
+
+    float s[3], e[3];
+    if (seg) {                      // k_traverse's endpoints of this very row (same arithmetic)
+        const float4 a = reinterpret_cast<const float4 *>(seg)[2 * (size_t)r];
+        const float4 b = reinterpret_cast<const float4 *>(seg)[2 * (size_t)r + 1];
+        s[0] = a.x; s[1] = a.y; s[2] = a.z;
+        e[0] = b.x; e[1] = b.y; e[2] = b.z;
+    } else if (ray_idxs) {
+        sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            s[i] = starts[3 * r + i];
+            e[i] = ends[3 * r + i];
+        }
+    }
+
+    if (SIM == 0) {
+        for (int k = lane; k < p.D; k += WAVE) Sl[k] = S_in[(size_t)r * p.D + k];
+    } else {
+        if (SIM == 1)
+            sweep_generic(p, fv, fv_table, P, s, e, lane, Sl);
+        else
+            sweep_coop<NV, LPS>(p, fv, fv_table, P, s, e, lane, Sl);
+        wave_sync();
+        softmax_column<MAPMODE == 2>(p.D, lane, Sl);
+    }
+    wave_sync();
+
+    if (MAPMODE == 0) {
+        for (int k = lane; k < p.D; k += WAVE) S_planes[(size_t)r * p.D + k] = Sl[k];
+        if (depth_from_planes) {
+            // similarities.py:199-227: points, first arg-max plane, distance to the camera
+            float best = -INFINITY;
+            int best_k = 0;
+            for (int k = lane; k < p.D; k += WAVE) {
+                float pt[3];
+                plane_point(s, e, k, p.D, pt);
+                reinterpret_cast<float4 *>(points)[(size_t)r * p.D + k] =
+                    make_float4(pt[0], pt[1], pt[2], 1.0f);
+                if (Sl[k] > best) {
+                    best = Sl[k];
+                    best_k = k;
+                }
+            }
+            // first maximum: larger value wins, then smaller index
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o);
+                const int ok = __shfl_xor(best_k, o);
+                if (ob > best || (ob == best && ok < best_k)) {
+                    best = ob;
+                    best_k = ok;
+                }
+            }
+            if (lane == 0) {
+                float pt[3];
+                plane_point(s, e, best_k, p.D, pt);
+                float sum = 0.0f;
+                for (int i = 0; i < 3; i++) {
+                    const float d = pt[i] - cc[i];
+                    sum += d * d;
+                }
+                depth_from_planes[r] = sqrtf(sum);
+            }
+        }
+        return;
+    }
+
+    const int count = min(uniform(rvc[r]), p.M);
+    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+    float *out = S_voxel + (size_t)r * p.M;
+    // MAPMODE 2 = the resident path: value-only divisions through the hardware reciprocal
+    // (the plane index walk inside stays IEEE); MAPMODE 1 = K6 / K11, reference arithmetic
+    const float srsum =
+        map_planes_to_voxels<PACKED, MAPMODE == 2>(p, axes, vrow, count, s, e, Sl, vals, lane);
+    if (MAPMODE == 1) {
+        for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
+    } else {
+        float sum = 0.0f;
+        const float rs = __builtin_amdgcn_rcpf(srsum);
+        for (int i = lane; i < count; i += WAVE) {
+            const float v = clampf(vals[i] * rs, (float)1e-5, (float)(1 - 1e-5));
+            vals[i] = v;
+            sum += v;
+        }
+        sum = __builtin_amdgcn_rcpf(wave_sum(sum));
+        // streamed out, read again only by later kernels: keep it out of the L2 the feature
+        // gathers live in
+        for (int i = lane; i < count; i += WAVE) __builtin_nontemporal_store(vals[i] * sum, out + i);
+    }
+}
+
