@@ -4,6 +4,9 @@ import sys
 import numpy as np
 import pytest
 
+# the MV-CNN twin's convolutions go through MIOpen: no exhaustive kernel search in tests
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
