@@ -436,7 +436,9 @@ class RayNetForwardPass(ForwardPass):
             lo, hi = shard_bounds(total, rank, world)
             lists[r] = rays
             shards.append((rays[lo:hi], lo, hi, total))
-        npad = max([len(sh[0]) for sh in shards] + [1])
+        # rows per image: the largest shard ANY rank holds (the same number on every rank, the
+        # depth maps are exchanged with an all-gather), rounded to whole scatter tiles
+        npad = max([(sh[3] + world - 1) // world for sh in shards] + [1])
         npad = (npad + 255) // 256 * 256            # scatter tiles never straddle two images
         vox_all = torch.empty((V * npad, M), dtype=torch.int32, device=dev)
         Sr_all = torch.empty((V * npad, M), dtype=torch.float32, device=dev)
@@ -570,17 +572,18 @@ class RayNetForwardPass(ForwardPass):
             centers = cam_dev[:, 12 * N + 12:].contiguous()
             ctx.scene_depth(Sr_all, vox_all, rvc_all, acc_in, msgs_all, centers, None, depth_all,
                             rays_per_center=npad)
-            # every rank writes its slices into a zeroed scene-wide map; ONE all-reduce
-            # (disjoint slices, zeros elsewhere) hands every rank the complete maps
-            offs = np.concatenate([[0], np.cumsum([per_image[r]["total"] for r in refs])])
-            merged = torch.zeros((int(offs[-1]),), dtype=torch.float32, device=dev)
+            # ONE all-gather of the ranks' row blocks (each rank sends only its own rows), then
+            # every rank stitches the per-image ray lists back together
+            flat = torch.empty((world * n_all,), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(flat, depth_all)
+            gathered = flat.view(world, n_all)
             for k, r in enumerate(refs):
-                st = per_image[r]
-                merged[int(offs[k]) + st["lo"]:int(offs[k]) + st["hi"]] = \
-                    depth_all[st["row0"]:st["row0"] + st["n"]]
-            dist.all_reduce(merged, op=dist.ReduceOp.SUM)
-            for k, r in enumerate(refs):
-                pending.append((r,) + to_host(merged[int(offs[k]):int(offs[k + 1])], r))
+                total = per_image[r]["total"]
+                pieces = []
+                for q in range(world):
+                    lo_q, hi_q = shard_bounds(total, q, world)
+                    pieces.append(gathered[q, k * npad:k * npad + (hi_q - lo_q)])
+                pending.append((r,) + to_host(torch.cat(pieces), r))
         for r in refs:
             st = per_image[r]
             self.messages.put(r, st["msgs"], st["rvc"])
