@@ -512,11 +512,9 @@ class RayNetForwardPass(ForwardPass):
                 if world > 1:      # integer sum: the same bits whatever the ring order
                     dist.all_reduce(acc_part, op=dist.ReduceOp.SUM)
                 ctx.acc_combine_fixed(acc_part, prior, acc_next)
-            elif world > 1:
-                ctx.acc_reduce_local(acc_part, acc_next)
-                dist.all_reduce(acc_next, op=dist.ReduceOp.SUM)
-                ctx.acc_add_prior(acc_next, prior)
             else:
+                if world > 1:      # partial sums of all ranks, then the prior once
+                    dist.all_reduce(acc_part, op=dist.ReduceOp.SUM)
                 ctx.acc_combine(acc_part, prior, acc_next)
             acc_in, acc_next = acc_next, acc_in
         self.accumulator = ctx.acc_to_grid(acc_in)
