@@ -112,6 +112,13 @@ class Oracle(object):
     def max_threads():
         return int(_load().rno_max_threads())
 
+    @staticmethod
+    def set_robust_messages(on):
+        """Process-wide: BP messages in the numerically robust form the HIP kernels use
+        (direct suffix sum, log pos - log neg) instead of the reference's literal sequence;
+        see raynet_oracle.c.  Off by default."""
+        _load().rno_set_robust_messages(1 if on else 0)
+
     # -- a1 ---------------------------------------------------------------
     def sample(self, ray_idxs, P_inv, center):
         ray_idxs = _i32(ray_idxs)

@@ -349,11 +349,53 @@ static void clip_and_renorm(const float *S, int count, float *Sr) {
 /* One BP sweep for one ray.  msgs_in and msgs_out may alias (the reference
  * always aliases them).  acc_out += message, element-wise, non-atomically
  * unless atomic != 0.  Sr is count floats of scratch. */
+/* 0 (default): the reference's message arithmetic, mrf_bp.cu:136-167, to the letter.
+ * 1: the numerically robust form the HIP kernels use -- the suffix sum
+ *    sum_{j>i} w_j accumulated directly instead of (cumsum1 - cumsum2), and the message as
+ *    log(pos) - log(neg) instead of log(p) - log(1 - p).  Same mathematics; it exists so that
+ *    full-size runs, where the literal form overflows to +inf in some voxels, still have a
+ *    finite CPU statement to be compared with (tools/fullsize_parity.py). */
+static int g_robust_messages = 0;
+void rno_set_robust_messages(int on) { g_robust_messages = on; }
+
 void rno_bp_ray(const rno_config *c, const float *S, const int32_t *rvi, int count,
                 const float *acc_in, const float *msgs_in, float *acc_out,
                 float *msgs_out, float *Sr, int atomic) {
     if (count <= 1) return; /* Q4: mrf_np.py:300 */
     clip_and_renorm(S, count, Sr);
+    if (g_robust_messages) {
+        float *w = (float *)malloc(sizeof(float) * 3 * (size_t)count);
+        float *ov = w + count, *Tp = w + 2 * count;
+        float cumprod = 1.0f;
+        for (int i = 0; i < count; i++) {
+            ov[i] = occupancy_to_ray(acc_in[grid_index(c, rvi + 3 * i)], msgs_in[i]);
+            Tp[i] = cumprod;
+            w[i] = ov[i] * cumprod * Sr[i];
+            cumprod *= (1.0f - ov[i]);
+        }
+        float suffix = 0.0f, prefix = 0.0f;
+        for (int i = count - 1; i >= 0; i--) {       /* msgs_out[i] <- suffix, for now */
+            msgs_out[i] = suffix;
+            suffix += w[i];
+        }
+        for (int i = 0; i < count; i++) {
+            float pos = prefix + Tp[i] * Sr[i];
+            float neg = prefix + msgs_out[i] / (1.0f - ov[i]);
+            prefix += w[i];
+            msgs_out[i] = logf(pos) - logf(neg);
+        }
+        free(w);
+        for (int i = 0; i < count; i++) {
+            float *dst = acc_out + grid_index(c, rvi + 3 * i);
+            if (atomic) {
+#pragma omp atomic
+                *dst += msgs_out[i];
+            } else {
+                *dst += msgs_out[i];
+            }
+        }
+        return;
+    }
 
     /* pass 1 (mrf_bp.cu:115-133): total of o_j * prod_{k<j}(1-o_k) * s_j */
     float cumsum1 = 0.0f, cumprod = 1.0f, cumprod_prev;
