@@ -1,0 +1,62 @@
+"""Host-side pieces of the resident path that need no GPU: the patch row order, the lazily
+cleared message container, ray sharding."""
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.mark.parametrize("H,W,tx,ty,along", [(480, 640, 16, 16, True), (37, 53, 16, 16, False),
+                                              (33, 17, 8, 32, True), (16, 16, 16, 16, False)])
+def test_tile_order_is_a_permutation_of_compact_patches(H, W, tx, ty, along):
+    from raynet_amd.forward_pass import tile_order
+    n = H * W
+    order = tile_order(torch.arange(n, dtype=torch.int32), H, W, tx, ty, along_rows=along).numpy()
+    assert order.dtype == np.int32 and np.array_equal(np.sort(order), np.arange(n))
+    x, y = order // H, order % H
+    # every run of tx*ty consecutive rows that starts on a patch boundary of a FULL patch
+    # covers exactly that patch
+    if H % ty == 0 and W % tx == 0:
+        for start in range(0, n, tx * ty):
+            px, py = x[start:start + tx * ty], y[start:start + tx * ty]
+            assert px.max() - px.min() == tx - 1 and py.max() - py.min() == ty - 1
+        # patches are enumerated along the requested direction
+        first = order[::tx * ty]
+        fx, fy = first // H // tx, first % H // ty
+        key = fy * (W // tx) + fx if along else fx * (H // ty) + fy
+        assert np.array_equal(key, np.arange(len(first)))
+    # a subset of the rays (filter_out_rays) keeps the relative order of the full list
+    rng = np.random.default_rng(0)
+    keep = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.int32)
+    sub = tile_order(torch.from_numpy(keep), H, W, tx, ty, along_rows=along).numpy()
+    assert np.array_equal(sub, order[np.isin(order, keep)])
+
+
+def test_messages_container_clears_tails_on_first_access():
+    from raynet_amd.forward_pass import _Messages
+    m = _Messages()
+    raw = torch.full((5, 8), 7.0)
+    counts = torch.tensor([0, 1, 3, 8, 5], dtype=torch.int32)
+    m.put(2, raw, counts)
+    assert 2 in m and float(raw.sum()) == 7.0 * 40          # nothing touched yet
+    got = m[2]
+    assert got is raw
+    expect = np.full((5, 8), 7.0, np.float32)
+    expect[0] = 0                      # count 0
+    expect[1] = 0                      # count 1: such rays send no message
+    expect[2, 3:] = 0
+    expect[4, 5:] = 0
+    assert np.array_equal(got.numpy(), expect)
+    raw[3, 0] = 1.0
+    assert float(m[2][3, 0]) == 1.0    # cleared once, not again
+    m[9] = torch.ones((2, 2))          # plain assignment (the reference-schedule path)
+    assert float(m[9].sum()) == 4.0
+
+
+def test_shard_bounds_cover_the_list():
+    from raynet_amd.forward_pass import shard_bounds
+    for n in (0, 1, 7, 307200, 307201):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
