@@ -232,6 +232,13 @@ def main():
                           "sweep with the oracle's fused K1/K2 (oracle/raynet_oracle.c, OpenMP), "
                           "%.1f s" % (n, rays_per_step, tc))
 
+    feat_per_ray = 4.0 * (gp.neighbors + 1) * cfg["F"] * (H + cfg["padding"] + 1) * \
+        (W + cfg["padding"] + 1) / (H * W)
+    path_bytes = rays_per_step * (3 * (feat_per_ray + 20 * mean_vox) + feat_per_ray + 8 * mean_vox + 4)
+    path_gbps = path_bytes / elapsed * args.steps / 1e9
+    path_roofline = dict(bytes_per_ray=round(path_bytes / rays_per_step, 1),
+                         achieved=round(path_gbps, 1), peak=HBM_PEAK_GBS * world, unit="GB/s",
+                         frac=round(path_gbps / (HBM_PEAK_GBS * world), 4))
     if rank == 0:
         result = {
             "metric": "rays/sec (whole node) at %d views x %d depths x %d^3 voxels" % (
@@ -254,6 +261,10 @@ def main():
                        if world > 1 else "single GPU",
                        "mean_voxels_per_ray": round(mean_vox, 2)},
             "ray_sweeps_per_s": round(4 * value, 1),
+            # SURVEY.md 8(d)'s whole-path figure: (3 B_bp + B_de) bytes per ray, B_bp = 4NF HfWf/HW
+            # + 20 c, B_de = 4NF HfWf/HW + 8 c + 4 (features once per sweep, per traversed voxel:
+            # gather 4 + msg 4 + 4 + atomic RMW 8), over the step's wall time
+            "path_roofline": path_roofline,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": kernels,
