@@ -1,6 +1,8 @@
 """RayNetForwardPass (the reference's ForwardPass API) on the GPU: the resident
 schedule vs the literal K1/K2 schedule vs the oracle, the MV-CNN twin as model, the
 other two drivers, and size-independent properties at BASELINE.json's full size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -440,3 +442,37 @@ def test_full_size_parity_with_the_oracle(torch, oracle_mod):
             assert (d > 1e-4).sum() <= 20, int((d > 1e-4).sum())
     finally:
         oracle_mod.Oracle.set_robust_messages(False)
+
+
+def test_forward_pass_script_on_a_restrepo_directory(torch, tmp_path):
+    """The caller of the path (scripts/forward_pass.py:29-146): a Restrepo-layout directory in,
+    depth_%03d.npy files out, through the loader, the MV-CNN twin and the raynet factory."""
+    from PIL import Image as PILImage
+    from raynet_amd.scripts.forward_pass import main
+    from raynet_amd.synthetic import ring_cameras
+    from test_scene_loaders import _write_scene_info
+    H, W = 24, 32
+    base = tmp_path / "scene"
+    (base / "imgs").mkdir(parents=True)
+    (base / "cams_krt").mkdir()
+    rng = np.random.default_rng(0)
+    for i, cam in enumerate(ring_cameras(5, H, W, focal=1.5 * H)):
+        PILImage.fromarray((rng.random((H, W, 3)) * 255).astype(np.uint8)).save(
+            str(base / "imgs" / ("frame_%03d.png" % i)))
+        with open(str(base / "cams_krt" / ("camera_%03d.txt" % i)), "w") as f:
+            np.savetxt(f, cam.K)
+            f.write("\n")
+            np.savetxt(f, cam.R)
+            f.write("\n")
+            np.savetxt(f, cam.t.reshape(1, 3))
+    _write_scene_info(str(base), [-1, -1, -1, 1, 1, 1])
+    out = tmp_path / "out"
+    rc = main([str(base), str(out), "--depth_planes", "16", "--grid_shape", "32,32,32",
+               "--maximum_number_of_marched_voxels", "96", "--start_end", "0,3",
+               "--forward_pass_factory", "raynet", "--rays_batch", "500"])
+    assert rc == 0
+    files = sorted(os.listdir(str(out)))
+    assert files == ["depth_000.npy", "depth_001.npy", "depth_002.npy"]
+    for f in files:
+        d = np.load(str(out / f))
+        assert d.shape == (H, W) and d.dtype == np.float32 and np.isfinite(d).all() and (d > 0).all()
