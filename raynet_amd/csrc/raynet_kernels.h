@@ -218,7 +218,69 @@ __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureView
 #ifndef RN_SWEEP_UNROLL2_MAX_VIEWS
 #define RN_SWEEP_UNROLL2_MAX_VIEWS 6
 #endif
-template <int NV, int LPS>
+// x + (x of the lane the DPP control names), one VALU instruction, no LDS round trip.
+// quad_perm:[1,0,3,2] / [2,3,0,1] = xor 1 / xor 2; row_half_mirror pairs lane i with 7-i of
+// its group of 8, which sums the two quads once they are quad-uniform.
+#define RN_ADD_DPP(OUT, MOVED, STAY, CTRL)                                                   \
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 " CTRL " row_mask:0xf bank_mask:0xf"           \
+        : "=v"(OUT) : "v"(MOVED), "v"(STAY))
+#define RN_DPP_XOR1 "quad_perm:[1,0,3,2]"
+#define RN_DPP_XOR2 "quad_perm:[2,3,0,1]"
+#define RN_DPP_MIRROR8 "row_half_mirror"
+
+// one load round of the cooperative sweep: this lane's 4*V4 channels of plane `src` (within
+// the chunk) in every view, multiplied out over the view pairs; returns the lane's partial
+template <int NV, int V4>
+__device__ __forceinline__ float sweep_round(const float *const (&vbase)[NV], const int (&offb)[NV],
+                                             int src, unsigned part_bytes) {
+    // lane's 16*V4 bytes of every view's vector, as channel pairs: the packed FMAs below
+    // then work on the register pairs exactly as the loads deliver them
+    float2v f2[NV][2 * V4];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        // byte offset from a uniform GLOBAL base: loads with a 32-bit register offset
+        // (global_load ... s[base]), no 64-bit address arithmetic per lane
+        const unsigned ob = (unsigned)__shfl(offb[v], src) + part_bytes;
+        typedef const __attribute__((address_space(1))) char *gptr;
+        typedef const __attribute__((address_space(1))) float4v *gptr4;
+#pragma unroll
+        for (int q = 0; q < V4; q++) {
+            const float4v f = *(gptr4)((gptr)vbase[v] + ob + 16u * q);
+            f2[v][2 * q] = float2v{f.x, f.y};
+            f2[v][2 * q + 1] = float2v{f.z, f.w};
+        }
+    }
+    // sum over view pairs i<j of <f_i, f_j>, as  sum_j <f_0 + ... + f_{j-1}, f_j>  on this
+    // lane's channels: NV-1 packed FMAs and NV-2 packed adds per channel pair instead
+    // of NV(NV-1)/2 products.  This is the only place where multiply-adds may fuse and
+    // where the summation order departs from the reference's serial pair loop (the
+    // kernels are VALU-issue bound; tolerance-tested against the oracle).
+    float acc;
+    {
+#pragma clang fp contract(fast)
+        float2v run[2 * V4], a2[2 * V4];
+#pragma unroll
+        for (int c = 0; c < 2 * V4; c++) {
+            run[c] = f2[0][c];
+            a2[c] = float2v{0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 1; j < NV; j++) {
+#pragma unroll
+            for (int c = 0; c < 2 * V4; c++) {
+                a2[c] = run[c] * f2[j][c] + a2[c];
+                if (j + 1 < NV) run[c] += f2[j][c];
+            }
+        }
+        float2v t = a2[0];
+#pragma unroll
+        for (int c = 1; c < 2 * V4; c++) t += a2[c];
+        acc = t.x + t.y;
+    }
+    return acc;
+}
+
+template <int NV, int LPS, bool FAST = false>
 __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &fv,
                                            const float *const *__restrict__ tbl,
                                            const float *__restrict__ P, const float s[3],
@@ -230,6 +292,7 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
     for (int v = 0; v < NV; v++) vbase[v] = tbl ? tbl[v] : fv.v[v];
     const int sub = lane / LPS;           // which plane of the group
     const int part = lane % LPS;          // which float4 of the vector
+    const unsigned part_bytes = (16u * V4) * (unsigned)part;
     const int pairs = (NV * (NV - 1)) / 2;
     for (int base = 0; base < p.D; base += WAVE) {
         // lane k projects plane base+k into every view
@@ -242,60 +305,41 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             for (int v = 0; v < NV; v++) offb[v] = feature_offset(p, P + 12 * v, point) * 4;
         }
         float mine = 0.0f;
-        // two rounds of loads in flight while the view count leaves registers for it
-#pragma clang loop unroll_count(NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? 2 : 1)
-        for (int it = 0; it < LPS; it++) {
-            const int src = it * SPL + sub;   // plane (within the chunk) this lane helps with
-            // lane's 16*V4 bytes of every view's vector, as channel pairs: the packed FMAs below
-            // then work on the register pairs exactly as the loads deliver them
-            float2v f2[NV][2 * V4];
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                // byte offset from a uniform GLOBAL base: loads with a 32-bit register offset
-                // (global_load ... s[base]), no 64-bit address arithmetic per lane
-                const unsigned ob = (unsigned)__shfl(offb[v], src) + (16u * V4) * (unsigned)part;
-                typedef const __attribute__((address_space(1))) char *gptr;
-                typedef const __attribute__((address_space(1))) float4v *gptr4;
-#pragma unroll
-                for (int q = 0; q < V4; q++) {
-                    const float4v f = *(gptr4)((gptr)vbase[v] + ob + 16u * q);
-                    f2[v][2 * q] = float2v{f.x, f.y};
-                    f2[v][2 * q + 1] = float2v{f.z, f.w};
-                }
+        int mine_round;         // which load round's plane this lane ends up holding
+        // The LPS partial sums of a plane are folded across its lanes with DPP adds (no LDS
+        // permutes).
+        if (LPS == 8 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS) {
+            // two rounds of loads in flight while the view count leaves registers for it, and
+            // their two reductions transposed: "odd" lanes fold round 2t+1, the others round
+            // 2t, so the xor-1 step serves both rounds at once.  The last step, lane i with
+            // 7-i, is the only 8-lane exchange DPP has on gfx9; it flips the lane parity, so
+            // "odd" is flipped in the upper quad to meet it.
+            const bool odd = (part ^ (part >> 2)) & 1;
+            mine_round = (part & ~1) | (int)odd;
+            for (int t = 0; t < LPS / 2; t++) {
+                const float a0 = sweep_round<NV, V4>(vbase, offb, (2 * t) * SPL + sub, part_bytes);
+                const float a1 = sweep_round<NV, V4>(vbase, offb, (2 * t + 1) * SPL + sub, part_bytes);
+                const float stay = odd ? a1 : a0, moved = odd ? a0 : a1;
+                float r;
+                RN_ADD_DPP(r, moved, stay, RN_DPP_XOR1);
+                RN_ADD_DPP(r, r, r, RN_DPP_XOR2);
+                RN_ADD_DPP(r, r, r, RN_DPP_MIRROR8);
+                if ((part >> 1) == t) mine = r;
             }
-            // sum over view pairs i<j of <f_i, f_j>, as  sum_j <f_0 + ... + f_{j-1}, f_j>  on this
-            // lane's channels: NV-1 packed FMAs and NV-2 packed adds per channel pair instead
-            // of NV(NV-1)/2 products.  This is the only place where multiply-adds may fuse and
-            // where the summation order departs from the reference's serial pair loop (the
-            // kernels are VALU-issue bound; tolerance-tested against the oracle).
-            float acc;
-            {
-#pragma clang fp contract(fast)
-                float2v run[2 * V4], a2[2 * V4];
-#pragma unroll
-                for (int c = 0; c < 2 * V4; c++) {
-                    run[c] = f2[0][c];
-                    a2[c] = float2v{0.f, 0.f};
-                }
-#pragma unroll
-                for (int j = 1; j < NV; j++) {
-#pragma unroll
-                    for (int c = 0; c < 2 * V4; c++) {
-                        a2[c] = run[c] * f2[j][c] + a2[c];
-                        if (j + 1 < NV) run[c] += f2[j][c];
-                    }
-                }
-                float2v t = a2[0];
-#pragma unroll
-                for (int c = 1; c < 2 * V4; c++) t += a2[c];
-                acc = t.x + t.y;
+        } else {
+            static_assert(LPS <= 8, "sweep_coop folds at most 8 lanes per plane");
+            mine_round = part;
+            for (int it = 0; it < LPS; it++) {
+                float acc = sweep_round<NV, V4>(vbase, offb, it * SPL + sub, part_bytes);
+                if (LPS >= 2) RN_ADD_DPP(acc, acc, acc, RN_DPP_XOR1);
+                if (LPS >= 4) RN_ADD_DPP(acc, acc, acc, RN_DPP_XOR2);
+                if (LPS >= 8) RN_ADD_DPP(acc, acc, acc, RN_DPP_MIRROR8);
+                if (part == it) mine = acc;
             }
-#pragma unroll
-            for (int m = 1; m < LPS; m <<= 1) acc += __shfl_xor(acc, m);
-            if (part == it) mine = acc;   // lane (sub, part) keeps plane part*SPL + sub
         }
-        const int k = base + part * SPL + sub;
-        if (k < p.D) Sl[k] = mine / pairs;
+        const int k = base + mine_round * SPL + sub;
+        // FAST (resident path): a constant factor of the softmax's input, value-only
+        if (k < p.D) Sl[k] = FAST ? mine * (1.0f / pairs) : mine / pairs;
     }
 }
 

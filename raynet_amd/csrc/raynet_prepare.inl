@@ -241,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_map(
         if (SIM == 1)
             sweep_generic(p, fv, fv_table, P, s, e, lane, Sl);
         else
-            sweep_coop<NV, LPS>(p, fv, fv_table, P, s, e, lane, Sl);
+            sweep_coop<NV, LPS, MAPMODE == 2>(p, fv, fv_table, P, s, e, lane, Sl);
         wave_sync();
         softmax_column<MAPMODE == 2>(p.D, lane, Sl);
     }
