@@ -281,6 +281,10 @@ int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *
  * (the gaps between launches = what the host side costs; tools/timeline.py) */
 int rn_prof_offsets(rn_ctx *ctx, float *start_ms_host);
 
+/* Self-test of the exact arithmetic shortcut of the index maps (raynet_kernels.h:
+ * round_half_away), for tests/: out is [2][n] -- roundf(a), round_half_away(a). */
+int rn_selftest_arith(rn_ctx *ctx, int32_t n, const float *a, float *out, void *stream);
+
 /* ---- differentiable MRF block (training) --------------
  * The reference builds this block from TensorFlow ops and lets autodiff
  * differentiate it (raynet/tf_implementations/forward_backward_pass.py:194-246,

@@ -106,6 +106,7 @@ SIGNATURES = {
     "rn_consistency_tau": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "rn_nearest_neighbors": [_P, _I, _P, _I, _P, _P, _P, _P],
     "rn_prof_offsets": [_P, _P],
+    "rn_selftest_arith": [_P, _I, _P, _P, _P],
     "rn_timer_start": [_P, _P],
     "rn_timer_stop": [_P, _P, ctypes.POINTER(_F)],
 }

@@ -67,6 +67,14 @@ __global__ void k_acc_combine(float *part, int copies, int64_t G, float prior, f
         out[i] = add_prior ? prior + s : s;
     }
 }
+// the exact arithmetic shortcut next to the expression it replaces (rn_selftest_arith)
+__global__ __launch_bounds__(BLOCK) void k_selftest_arith(int n, const float *__restrict__ a,
+                                                          float *out) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    out[i] = roundf(a[i]);
+    out[(size_t)n + i] = round_half_away(a[i]);
+}
 // resident (bricked) accumulator <-> the reference's [gx][gy][gz] array
 template <bool TO_GRID>
 __global__ void k_acc_regrid(Params p, const float *__restrict__ src, float *dst) {
@@ -854,6 +862,14 @@ int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *
         if (n_rays_host) n_rays_host[i] = ctx->prof_rays[i];
     }
     *count = n;
+    return RN_OK;
+}
+
+int rn_selftest_arith(rn_ctx *ctx, int32_t n, const float *a, float *out, void *stream) {
+    if (ctx && n == 0) return RN_OK;
+    if (!ctx || n < 0 || !a || !out) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_selftest_arith, dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream), n, a, out);
+    RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }
 

@@ -93,15 +93,32 @@ __device__ __forceinline__ float lane63(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 __device__ __forceinline__ int lane63i(int x) { return __builtin_amdgcn_readlane(x, 63); }
+// Wave-wide reductions on the VALU only (no LDS permutes): xor-1 / xor-2 inside the quads,
+// 7-i inside the half rows, 15-i inside the rows (every lane then holds its row's result),
+// then the two row broadcasts of the scan; lane 63 ends up with the result of the whole
+// wave and hands it out through an SGPR.  All 64 lanes must be active.
+#define RN_WAVE_REDUCE(OP, X)                                                    \
+    RN_SCAN_STEP(OP, X, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");       \
+    RN_SCAN_STEP(OP, X, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");       \
+    RN_SCAN_STEP(OP, X, "row_half_mirror row_mask:0xf bank_mask:0xf");           \
+    RN_SCAN_STEP(OP, X, "row_mirror row_mask:0xf bank_mask:0xf");                \
+    RN_SCAN_STEP(OP, X, "row_bcast:15 row_mask:0xa bank_mask:0xf");              \
+    RN_SCAN_STEP(OP, X, "row_bcast:31 row_mask:0xc bank_mask:0xf")
 __device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+    RN_WAVE_REDUCE("v_add_f32_dpp", x);
+    return lane63(x);
 }
 __device__ __forceinline__ float wave_max(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
-    return x;
+    RN_WAVE_REDUCE("v_max_f32_dpp", x);
+    return lane63(x);
+}
+__device__ __forceinline__ int wave_max_i(int x) {
+    RN_WAVE_REDUCE("v_max_i32_dpp", x);
+    return lane63i(x);
+}
+__device__ __forceinline__ int wave_min_i(int x) {
+    RN_WAVE_REDUCE("v_min_i32_dpp", x);
+    return lane63i(x);
 }
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // LDS hand-over between lanes of ONE wavefront: the hardware keeps a wave's DS
@@ -113,6 +130,19 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ float clampf(float x, float a, float b) {
     return fminf(fmaxf(x, a), b);   // utils.cu:1-3
+}
+
+// ------------------------------------------------- exact arithmetic shortcuts
+// Bit-identical, cheaper forms of expressions whose results feed INDEX maps (DESIGN.md
+// section 6).  Nothing here is an approximation.  (Sharing one refined reciprocal between
+// quotients of the same divisor -- x/n and y/n, k*(e-s)/(D-1), sum/|ray|^2 -- is also exact
+// inside a range check, saves ~130 VALU instructions per ray and was measured SLOWER with
+// its fallback branch in place: the kernel waits on its gathers, not on VALU issue.)
+//
+// roundf(x) == trunc(x + copysign(pred(0.5), x)) for every one of the 2^32 floats
+// (tools/verify_round_trick.c walks them all): 3 instructions instead of 6.
+__device__ __forceinline__ float round_half_away(float x) {
+    return __builtin_truncf(x + __builtin_copysignf(0x1.fffffep-2f, x));
 }
 
 // ------------------------------------------------------------------- a1
@@ -171,6 +201,27 @@ __device__ __forceinline__ int feature_offset(const Params &p, const float *__re
     fy = min(max(fy, 0), p.H);
     if (fx == 0 || fy == 0) fx = fy = 0;
     return (fy * p.Wf + fx) * p.F;
+}
+
+// The same map for the cooperative sweep (F*4 = 1 << LOG2_VEC_BYTES bytes per vector), as a
+// BYTE offset and with fewer instructions, every step exact: the 3-instruction round,
+// `+ padding - half` as one addition (exact on integer-valued floats; beyond 2^24 the clamp
+// decides either way), the clamp as one v_med3_f32 before the conversion (NaN -> 0 like the
+// saturating v_cvt_i32_f32), a 24-bit multiply and a shift instead of two 32-bit multiplies.
+template <int LOG2_VEC_BYTES>
+__device__ __forceinline__ int feature_offset_bytes(const Params &p,
+                                                    const float *__restrict__ Pv,
+                                                    const float point[3], float pad_shift) {
+    float x = 0.0f, y = 0.0f, n = 0.0f;
+    x += Pv[0] * point[0]; x += Pv[1] * point[1]; x += Pv[2] * point[2]; x += Pv[3] * 1;
+    y += Pv[4] * point[0]; y += Pv[5] * point[1]; y += Pv[6] * point[2]; y += Pv[7] * 1;
+    n += Pv[8] * point[0]; n += Pv[9] * point[1]; n += Pv[10] * point[2]; n += Pv[11] * 1;
+    const float rx = round_half_away(x / n) + pad_shift;
+    const float ry = round_half_away(y / n) + pad_shift;
+    const unsigned fx = (unsigned)(int)__builtin_amdgcn_fmed3f(rx, 0.0f, (float)p.W);
+    const unsigned fy = (unsigned)(int)__builtin_amdgcn_fmed3f(ry, 0.0f, (float)p.H);
+    const unsigned off = (__umul24(fy, (unsigned)p.Wf) + fx) << LOG2_VEC_BYTES;
+    return min(fx, fy) == 0u ? 0 : (int)off;
 }
 
 __device__ __forceinline__ void plane_point(const float s[3], const float e[3], int k, int D,
@@ -294,6 +345,10 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
     const int part = lane % LPS;          // which float4 of the vector
     const unsigned part_bytes = (16u * V4) * (unsigned)part;
     const int pairs = (NV * (NV - 1)) / 2;
+    // F = 4*V4*LPS floats per vector
+    constexpr int LOG2_VEC_BYTES = LPS * V4 == 8 ? 7 : LPS * V4 == 4 ? 6 : LPS * V4 == 2 ? 5 : 4;
+    static_assert((16 * V4 * LPS) == (1 << LOG2_VEC_BYTES), "vector bytes must be a power of two");
+    const float pad_shift = (float)(p.padding - (p.padding - 1) / 2);
     for (int base = 0; base < p.D; base += WAVE) {
         // lane k projects plane base+k into every view
         int offb[NV];           // BYTE offset of the plane's feature vector in every view
@@ -302,7 +357,8 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             float point[3];
             plane_point(s, e, k, p.D, point);
 #pragma unroll
-            for (int v = 0; v < NV; v++) offb[v] = feature_offset(p, P + 12 * v, point) * 4;
+            for (int v = 0; v < NV; v++)
+                offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, P + 12 * v, point, pad_shift);
         }
         float mine = 0.0f;
         int mine_round;         // which load round's plane this lane ends up holding

@@ -183,8 +183,11 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
 //          1: map to voxels, write S_voxel = vals / sum             (K6 / K11 / K1 / K2 prefix)
 //          2: as 1, then clip_and_renorm (mrf_bp.cu:103-111) -> Sr  (resident-scene path)
 // Dynamic LDS: [axes gx+gy+gz][per wave: D plane column][per wave: M values]
+#ifndef RN_SWEEP_MIN_WAVES
+#define RN_SWEEP_MIN_WAVES 1
+#endif
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
-__global__ __launch_bounds__(BLOCK) void k_sweep_map(
+__global__ __launch_bounds__(BLOCK, RN_SWEEP_MIN_WAVES) void k_sweep_map(
     Params p, int n, const int32_t *__restrict__ ray_idxs, FeatureViews fv,
     const float *__restrict__ P, const float *__restrict__ P_inv, const float *__restrict__ cc,
     const float *__restrict__ starts, const float *__restrict__ ends,

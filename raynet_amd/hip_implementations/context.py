@@ -187,6 +187,10 @@ class HipContext(object):
         return [(self.KERNEL_NAMES.get(ids[i], str(ids[i])), int(rays[i]), float(ms[i]))
                 for i in range(n.value)]
 
+    def selftest_arith(self, a, out):
+        """out[2][n]: roundf(a), round_half_away(a) (tests only)."""
+        self._check(self.lib.rn_selftest_arith(self._h, a.numel(), _ptr(a), _ptr(out), _stream()))
+
     # -- thin wrappers; argument order is the header's ------------------------
     def fill_f32(self, t, value):
         self._check(self.lib.rn_fill_f32(self._h, _ptr(t), t.numel(), float(value), _stream()))

@@ -858,3 +858,29 @@ def test_scatter_levels_agree_and_fixed_point_is_level_independent(torch, oracle
         assert np.abs(floats[level] - floats[0]).max() < 2e-5 * scale
         assert np.array_equal(fixeds[level], fixeds[0])
     assert np.abs(fixeds[0] - floats[0]).max() < 2e-5 * scale
+
+
+def test_exact_arithmetic_shortcuts(torch, oracle_mod):
+    """round_half_away (3 instructions) == roundf bit for bit on the GPU: 4 M random bit
+    patterns plus the half-way edges.  (tools/verify_round_trick.c walks all 2^32 floats on
+    the CPU.)"""
+    o, _, _ = make_case(oracle_mod, CU["small"])
+    ctx = hip_ctx(o)
+    rng = np.random.default_rng(5)
+    n = 1 << 22
+    a = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32).copy()
+    k = np.arange(4096, dtype=np.float32)
+    edges = np.concatenate([k + 0.5, -(k + 0.5), np.nextafter(k + 0.5, 0).astype(np.float32),
+                            np.nextafter(k + 0.5, 1e9).astype(np.float32), k, -k,
+                            np.float32(2.0) ** np.arange(-45, 40, dtype=np.float32),
+                            np.float32(2.0) ** 23 + k, np.float32(2.0) ** 22 + k + 0.5])
+    a[:edges.size] = edges
+    out = torch.zeros((2, n), device="cuda")
+    ctx.selftest_arith(torch.from_numpy(a).cuda(), out)
+    out = out.cpu().numpy()
+    ok = np.isnan(a) | (out[0].view(np.uint32) == out[1].view(np.uint32))
+    assert ok.all(), "round_half_away differs from roundf"
+    with np.errstate(all="ignore"):
+        expect = np.where(np.isfinite(a), np.trunc(a.astype(np.float64) + np.copysign(0.5, a)), a)
+    fin = np.isfinite(a)
+    assert np.array_equal(out[0][fin], expect.astype(np.float32)[fin])
