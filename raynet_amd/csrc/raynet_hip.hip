@@ -880,6 +880,18 @@ int rn_prof_offsets(rn_ctx *ctx, float *start_ms_host) {
     return RN_OK;
 }
 
+#ifdef RN_PHASE_TIMERS
+int rn_debug_phase(unsigned long long *out_host, int reset) {
+    if (out_host &&
+        hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess)
+        return RN_ERR_HIP;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return RN_ERR_HIP;
+    }
+    return RN_OK;
+}
+#endif
 #ifdef RN_SCATTER_STATS
 int rn_debug_scatter_stats(unsigned long long *out_host, int reset) {
     if (out_host &&

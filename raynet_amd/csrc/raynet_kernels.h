@@ -469,7 +469,7 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
                                                       const int32_t *__restrict__ vrow,
                                                       int count, const float s[3],
                                                       const float e[3], const float *Sl,
-                                                      float *vals, int lane) {
+                                                      float *vals, int lane, int n_staged = 0) {
     const float eps = 1e-4f;
     float ray[3], ray_norm = 0.0f;
 #pragma unroll
@@ -486,7 +486,14 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
         float t = 0.0f;
         if (valid) {
             int x, y, z;
-            load_voxel<PACKED>(vrow, i, x, y, z);
+            if (PACKED && i < n_staged) {       // packed ids parked in vals[] by the caller
+                const int v = __builtin_bit_cast(int, vals[i]);
+                x = v >> 20;
+                y = (v >> 10) & 1023;
+                z = v & 1023;
+            } else {
+                load_voxel<PACKED>(vrow, i, x, y, z);
+            }
             float sum = 0.0f;
             float vd = axes[x];
             vd -= s[0];

@@ -183,6 +183,21 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
 //          1: map to voxels, write S_voxel = vals / sum             (K6 / K11 / K1 / K2 prefix)
 //          2: as 1, then clip_and_renorm (mrf_bp.cu:103-111) -> Sr  (resident-scene path)
 // Dynamic LDS: [axes gx+gy+gz][per wave: D plane column][per wave: M values]
+// -DRN_PHASE_TIMERS: where a k_sweep_map wavefront's cycles go (tools/phase_timers.py);
+// every 16th ray adds the s_memtime deltas between the marks to g_phase[]
+#ifdef RN_PHASE_TIMERS
+__device__ unsigned long long g_phase[16];
+#define RN_PHASE_DECL unsigned long long ph_t = clock64(); const bool ph_on = (r & 15) == 0
+#define RN_PHASE_MARK(K)                                                          \
+    do {                                                                          \
+        const unsigned long long ph_n = clock64();                                \
+        if (ph_on && lane == 0) atomicAdd(&g_phase[K], ph_n - ph_t);              \
+        ph_t = ph_n;                                                              \
+    } while (0)
+#else
+#define RN_PHASE_DECL
+#define RN_PHASE_MARK(K)
+#endif
 #ifndef RN_SWEEP_MIN_WAVES
 #define RN_SWEEP_MIN_WAVES 1
 #endif
@@ -220,6 +235,8 @@ __global__ __launch_bounds__(BLOCK, RN_SWEEP_MIN_WAVES) void k_sweep_map(
     int lane;
     int r = ray_of_wave(n, lane);
     if (r < 0) return;
+    RN_PHASE_DECL;
+    RN_PHASE_MARK(0);                      // (clock read only)
     if (order) r = uniform(order[r]);      // schedule only: which ray this wavefront takes
 
     float s[3], e[3];
@@ -238,6 +255,25 @@ __global__ __launch_bounds__(BLOCK, RN_SWEEP_MIN_WAVES) void k_sweep_map(
         }
     }
 
+    // The ray's voxel row is needed only after the sweep -- three dependent ~1.5k-cycle loads
+    // later if fetched there (tools/phase_timers.py).  Its count is fetched with the segment
+    // and the packed ids go straight from global memory into this wave's vals[] row (unused
+    // until the mapping) with LDS-DMA loads: no staging registers, and the sweep covers the
+    // latency.  LDS address = wave-uniform base + 4 * lane, which is the row's own layout.
+    int count = 0, n_staged = 0;
+    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
+    if (MAPMODE != 0) {
+        count = min(uniform(rvc[r]), p.M);
+        if (PACKED) {
+            typedef const __attribute__((address_space(1))) void *gptr;
+            typedef __attribute__((address_space(3))) void *lptr;
+            for (int c = 0; c < count; c += WAVE)
+                if (c + lane < p.M)
+                    __builtin_amdgcn_global_load_lds((gptr)(vrow + c + lane), (lptr)(vals + c), 4, 0, 0);
+            n_staged = (count + WAVE - 1) & ~(WAVE - 1);
+        }
+    }
+    RN_PHASE_MARK(1);                      // ray index + segment loads
     if (SIM == 0) {
         for (int k = lane; k < p.D; k += WAVE) Sl[k] = S_in[(size_t)r * p.D + k];
     } else {
@@ -246,9 +282,11 @@ __global__ __launch_bounds__(BLOCK, RN_SWEEP_MIN_WAVES) void k_sweep_map(
         else
             sweep_coop<NV, LPS, MAPMODE == 2>(p, fv, fv_table, P, s, e, lane, Sl);
         wave_sync();
+        RN_PHASE_MARK(2);                  // projection + feature gathers + pair sums
         softmax_column<MAPMODE == 2>(p.D, lane, Sl);
     }
     wave_sync();
+    RN_PHASE_MARK(3);                      // softmax
 
     if (MAPMODE == 0) {
         for (int k = lane; k < p.D; k += WAVE) S_planes[(size_t)r * p.D + k] = Sl[k];
@@ -290,13 +328,14 @@ __global__ __launch_bounds__(BLOCK, RN_SWEEP_MIN_WAVES) void k_sweep_map(
         return;
     }
 
-    const int count = min(uniform(rvc[r]), p.M);
-    const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
     float *out = S_voxel + (size_t)r * p.M;
+    if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the voxel row
     // MAPMODE 2 = the resident path: value-only divisions through the hardware reciprocal
     // (the plane index walk inside stays IEEE); MAPMODE 1 = K6 / K11, reference arithmetic
     const float srsum =
-        map_planes_to_voxels<PACKED, MAPMODE == 2>(p, axes, vrow, count, s, e, Sl, vals, lane);
+        map_planes_to_voxels<PACKED, MAPMODE == 2>(p, axes, vrow, count, s, e, Sl, vals, lane,
+                                                   n_staged);
+    RN_PHASE_MARK(4);                      // planes -> voxels
     if (MAPMODE == 1) {
         for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
     } else {
@@ -312,5 +351,9 @@ __global__ __launch_bounds__(BLOCK, RN_SWEEP_MIN_WAVES) void k_sweep_map(
         // gathers live in
         for (int i = lane; i < count; i += WAVE) __builtin_nontemporal_store(vals[i] * sum, out + i);
     }
+    RN_PHASE_MARK(5);                      // clip + renormalise + store
+#ifdef RN_PHASE_TIMERS
+    if (ph_on && lane == 0) atomicAdd(&g_phase[15], 1ull);
+#endif
 }
 
