@@ -398,10 +398,14 @@ class RayNetForwardPass(ForwardPass):
             cam_host[k, 12 * N + 12:] = center
         key = cam_host.tobytes()
         if self._cam_cache is None or self._cam_cache[0] != key:
-            self._cam_cache = (key, ctx.dev(cam_host))
+            # patches are enumerated along the direction of the neighbour views' epipolar
+            # lines (of the first reference image: one list serves the whole scene)
+            rows = bool(refs) and sweep_direction(
+                H, W, [scene.get_image(v) for v in views_of[refs[0]]]) == "rows"
+            self._cam_cache = (key, ctx.dev(cam_host), rows)
             if hasattr(ctx, "scatter_reset"):
                 ctx.scatter_reset()      # new cameras: the scatter re-learns its tile shape
-        cam_dev = self._cam_cache[1]
+        cam_dev, epipolar_rows = self._cam_cache[1], self._cam_cache[2]
 
         # K1 prefix once per reference image; the per-ray columns of ALL images live in one
         # scene-wide buffer each (image k owns rows [k*npad, k*npad + n)), so that every BP
@@ -411,12 +415,9 @@ class RayNetForwardPass(ForwardPass):
         shards = []
         lists = {}
         patch_rows = self.ray_tile is not None
-        # patches are enumerated along the direction of the neighbour views' epipolar lines
-        # (of the first reference image: one list serves the whole scene)
         along = os.environ.get("RAYNET_TILE_ALONG", "auto")
         along_rows = patch_rows and bool(refs) and (
-            along == "rows" or (along == "auto" and sweep_direction(
-                H, W, [scene.get_image(v) for v in views_of[refs[0]]]) == "rows"))
+            along == "rows" or (along == "auto" and epipolar_rows))
         for k, r in enumerate(refs):
             # the image's ray list in ROW order (what row i of its buffers holds)
             if self._filter_out_rays:
@@ -467,9 +468,10 @@ class RayNetForwardPass(ForwardPass):
             return orders[key]
 
         whole = not self._filter_out_rays and not self.rays_batch and V > 0
-        if whole:
+        if whole and not patch_rows and self.sweep_reorder:
+            # (patch rows take no sweep order at all, see order_for)
             modes = {sweep_direction(H, W, [scene.get_image(v) for v in views_of[r]]) for r in refs}
-            whole = len(modes) == 1 or not self.sweep_reorder
+            whole = len(modes) == 1
         if whole and hasattr(ctx, "scene_prepare_all"):
             # every image traverses / sweeps the same ray list: two launches for the scene
             ridx, lo, hi, total = shards[0]
