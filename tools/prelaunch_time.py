@@ -6,7 +6,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from raynet_amd.common.generation_parameters import GenerationParameters
 from raynet_amd.forward_pass import get_forward_pass_factory
 from raynet_amd.synthetic import make_synthetic_scene
-H, W, V = 480, 640, 5
+H, W, V = 480, int(os.environ.get("W", "640")), 5
 scene, bank = make_synthetic_scene(H=H, W=W, n_views=V, focal=1.5 * H)
 gp = GenerationParameters(depth_planes=64, neighbors=4, grid_shape=np.array([128]*3, np.int32),
                           max_number_of_marched_voxels=384, padding=11, gamma_mrf=0.05)
