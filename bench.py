@@ -49,6 +49,10 @@ CONFIGS = {
     # 8-GPU run has to do (debug only; no collectives)
     "eighth": dict(H=480, W=80, views=5, D=64, M=384, grid=(128, 128, 128), F=32, padding=11,
                    workload="480x80 strip of config 2 (debug only)"),
+    "quarter": dict(H=480, W=160, views=5, D=64, M=384, grid=(128, 128, 128), F=32, padding=11,
+                    workload="480x160 strip of config 2 (debug only)"),
+    "half": dict(H=480, W=320, views=5, D=64, M=384, grid=(128, 128, 128), F=32, padding=11,
+                 workload="480x320 strip of config 2 (debug only)"),
 }
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)

@@ -5,6 +5,7 @@ raynet/common/scene.py:22-141; `RestrepoScene` and `DTUScene` read the two on-di
 layouts the reference supports (scene.py:144-452, parse_input_data.py:13-58), SURVEY.md 8(f)
 row 4.  Host-side parsing only -- nothing here touches the GPU.
 """
+import functools
 import os
 import xml.etree.ElementTree as ET
 
@@ -72,6 +73,12 @@ def get_adjacent_frames_idxs(ref_idx, n_frames, n_adjacent, skip):
     return idxs
 
 
+@functools.lru_cache(maxsize=4096)
+def _adjacent_cached(i, n_images, neighbors):
+    # a pure function of three integers, asked for every reference image of every pass
+    return tuple(int(j) for j in get_adjacent_frames_idxs(i, n_images, neighbors, 0))
+
+
 def adjacent_views(i, n_images, neighbors):
     """The 'filesystem' neighbour rule of the reference (common/scene.py:41-57) as a list."""
     assert neighbors < n_images
@@ -106,7 +113,7 @@ class Scene(object):
                 self._camera_neighbors = distances.argsort()[:, 1:neighbors + 1]
             return [int(j) for j in self._camera_neighbors[i]]
         if self._select_neighbors_based_on == "filesystem":
-            return [int(j) for j in get_adjacent_frames_idxs(i, self.n_images, neighbors, 0)]
+            return list(_adjacent_cached(int(i), int(self.n_images), int(neighbors)))
         raise NotImplementedError()
 
     @property

@@ -297,6 +297,7 @@ class RayNetForwardPass(ForwardPass):
         self._ray_lists = {}
         self._cam_cache = None
         self._table_cache = None
+        self._stitch_cache = None
         self._side_stream = None
         self.ref_idx = -1
         self._ctx = None
@@ -572,18 +573,35 @@ class RayNetForwardPass(ForwardPass):
             centers = cam_dev[:, 12 * N + 12:].contiguous()
             ctx.scene_depth(Sr_all, vox_all, rvc_all, acc_in, msgs_all, centers, None, depth_all,
                             rays_per_center=npad)
-            # ONE all-gather of the ranks' row blocks (each rank sends only its own rows), then
-            # every rank stitches the per-image ray lists back together
-            flat = torch.empty((world * n_all,), dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(flat, depth_all)
-            gathered = flat.view(world, n_all)
+            # ONE all-gather of the ranks' row blocks (each rank sends only its own rows), ONE
+            # gather that puts every image's rows of every rank into pixel order (its index
+            # map depends on the ray lists and the sharding only: built once), ONE copy to the
+            # host.  Pixels without a ray (filtered out) read the zero behind the blocks.
+            HW = H * W
+            flat = torch.empty((world * n_all + 1,), dtype=torch.float32, device=dev)
+            flat[-1] = 0.0
+            dist.all_gather_into_tensor(flat[:-1], depth_all)
+            skey = (tuple(lists[r].data_ptr() for r in refs), tuple(len(lists[r]) for r in refs),
+                    world, npad, HW, str(dev))
+            if self._filter_out_rays or self._stitch_cache is None or self._stitch_cache[0] != skey:
+                src = torch.full((V * HW,), world * n_all, dtype=torch.int64, device=dev)
+                for k, r in enumerate(refs):
+                    total = per_image[r]["total"]
+                    rays = lists[r].long()
+                    for q in range(world):
+                        lo_q, hi_q = shard_bounds(total, q, world)
+                        src[k * HW + rays[lo_q:hi_q]] = (
+                            q * n_all + k * npad +
+                            torch.arange(hi_q - lo_q, dtype=torch.int64, device=dev))
+                self._stitch_cache = (skey, src, [lists[r] for r in refs])   # (keeps the lists alive)
+            maps = flat.index_select(0, self._stitch_cache[1])
+            host = torch.empty((V * HW,), dtype=torch.float32, pin_memory=cuda)
+            host.copy_(maps, non_blocking=True)
+            done = torch.cuda.Event() if cuda else None
+            if done is not None:
+                done.record()
             for k, r in enumerate(refs):
-                total = per_image[r]["total"]
-                pieces = []
-                for q in range(world):
-                    lo_q, hi_q = shard_bounds(total, q, world)
-                    pieces.append(gathered[q, k * npad:k * npad + (hi_q - lo_q)])
-                pending.append((r,) + to_host(torch.cat(pieces), r))
+                pending.append((r, host[k * HW:(k + 1) * HW], done if k == 0 else None))
         for r in refs:
             st = per_image[r]
             self.messages.put(r, st["msgs"], st["rvc"])

@@ -1,0 +1,69 @@
+"""What ONE rank of an N-rank run has to do, timed on one GPU: the sharded code path of
+RayNetForwardPass with the collectives stubbed out (all_reduce: nothing, all_gather: local
+copy).  The depth maps are wrong by construction (partial accumulators); the launches, their
+sizes and the host work are those of rank `RANK` of `N`.  Gives the ceiling of the strong
+scaling before any xGMI traffic:  t_1 / (N * t_N)."""
+import os, sys, time, types
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import raynet_amd.forward_pass as F
+from raynet_amd.common.generation_parameters import GenerationParameters
+from raynet_amd.synthetic import make_synthetic_scene
+H, W, V = 480, 640, 5
+scene, bank = make_synthetic_scene(H=H, W=W, n_views=V, F=32, padding=11, focal=1.5 * H, seed=1234)
+gp = GenerationParameters(depth_planes=64, neighbors=4, grid_shape=np.array([128] * 3, np.int32),
+                          max_number_of_marched_voxels=384, padding=11, gamma_mrf=0.05)
+
+
+class FakeDist(object):
+    ReduceOp = types.SimpleNamespace(SUM=0)
+
+    def __init__(self, world):
+        self.world = world
+
+    def all_reduce(self, t, op=None):
+        pass
+
+    def all_gather_into_tensor(self, out, inp):
+        out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
+
+
+res = {}
+for world in (1, 2, 4, 8):
+    for rank in sorted({0, world // 2}):
+        fake = FakeDist(world)
+        F._dist = (lambda f=fake, r=rank, w=world: (f, r, w)) if world > 1 else (lambda: (None, 0, 1))
+        fp = F.get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0)
+        def step():
+            for _ in fp.forward_pass(scene, (0, V, 1)):
+                pass
+        for _ in range(3):
+            step()
+        ctx = fp._ctx
+        torch.cuda.synchronize()
+        ctx.prof_begin(capacity=1024)
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        fam = {}
+        launches = ctx.prof_end()
+        for name, _, k_ms in launches:
+            fam[name] = fam.get(name, 0.0) + k_ms / n
+        if os.environ.get("TIMELINE") == "%d" % world and rank == 0:
+            end_prev = 0.0
+            per = len(launches) // n
+            for (name, _, k_ms), st in list(zip(launches, ctx.prof_starts))[per:3 * per]:
+                print("   %-10s start %8.3f  gap %7.3f  dur %7.3f" % (name, st, st - end_prev, k_ms))
+                end_prev = st + k_ms
+        res[(world, rank)] = ms
+        print("world %d rank %d: %.3f ms/step  kernels %.3f  (%s)" % (
+            world, rank, ms, sum(fam.values()), " ".join("%s=%.3f" % kv for kv in sorted(fam.items()))))
+t1 = res[(1, 0)]
+for world in (2, 4, 8):
+    t = max(v for (w, r), v in res.items() if w == world)
+    print("N=%d: compute-only ceiling of the strong scaling %.0f %%  (%.1f M rays/s)" % (
+        world, 100.0 * t1 / (world * t), V * H * W / t / 1e3))
