@@ -7,6 +7,14 @@ import os, sys, time, types
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+from raynet_amd import _lib
+if os.environ.get("RN_FLAGS"):      # A/B build of the library for this run only
+    import subprocess
+    so = os.path.join(REPO, "tools", "libraynet_hip_ab.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + _lib.HIPCC_FLAGS + os.environ["RN_FLAGS"].split() +
+                          ["-I", os.path.join(REPO, "include"),
+                           os.path.join(_lib.CSRC, "raynet_hip.hip"), "-o", so])
+    _lib.LIB_PATH = so
 import raynet_amd.forward_pass as F
 from raynet_amd.common.generation_parameters import GenerationParameters
 from raynet_amd.synthetic import make_synthetic_scene
@@ -30,7 +38,7 @@ class FakeDist(object):
 
 
 res = {}
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     for rank in sorted({0, world // 2}):
         fake = FakeDist(world)
         F._dist = (lambda f=fake, r=rank, w=world: (f, r, w)) if world > 1 else (lambda: (None, 0, 1))
@@ -62,8 +70,10 @@ for world in (1, 2, 4, 8):
         res[(world, rank)] = ms
         print("world %d rank %d: %.3f ms/step  kernels %.3f  (%s)" % (
             world, rank, ms, sum(fam.values()), " ".join("%s=%.3f" % kv for kv in sorted(fam.items()))))
-t1 = res[(1, 0)]
-for world in (2, 4, 8):
+t1 = res.get((1, 0))
+for world in ([2, 4, 8] if t1 else []):
+    if (world, 0) not in res:
+        continue
     t = max(v for (w, r), v in res.items() if w == world)
     print("N=%d: compute-only ceiling of the strong scaling %.0f %%  (%.1f M rays/s)" % (
         world, 100.0 * t1 / (world * t), V * H * W / t / 1e3))
