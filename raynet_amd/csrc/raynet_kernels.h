@@ -281,14 +281,22 @@ __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureView
 
 // one load round of the cooperative sweep: this lane's 4*V4 channels of plane `src` (within
 // the chunk) in every view, multiplied out over the view pairs; returns the lane's partial
-template <int NV, int V4>
+// REF_HELD: view 0's vector is the same for every plane of the chunk (see sweep_coop) and
+// comes in `ref` instead of being loaded again
+template <int NV, int V4, bool REF_HELD = false>
 __device__ __forceinline__ float sweep_round(const float *const (&vbase)[NV], const int (&offb)[NV],
-                                             int src, unsigned part_bytes) {
+                                             int src, unsigned part_bytes,
+                                             const float2v (&ref)[2 * V4]) {
     // lane's 16*V4 bytes of every view's vector, as channel pairs: the packed FMAs below
     // then work on the register pairs exactly as the loads deliver them
     float2v f2[NV][2 * V4];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
+        if (REF_HELD && v == 0) {
+#pragma unroll
+            for (int c = 0; c < 2 * V4; c++) f2[0][c] = ref[c];
+            continue;
+        }
         // byte offset from a uniform GLOBAL base: loads with a 32-bit register offset
         // (global_load ... s[base]), no 64-bit address arithmetic per lane
         const unsigned ob = (unsigned)__shfl(offb[v], src) + part_bytes;
@@ -331,6 +339,48 @@ __device__ __forceinline__ float sweep_round(const float *const (&vbase)[NV], co
     return acc;
 }
 
+// the LPS load rounds of one 64-plane chunk; returns the pair sum of the plane this lane ends
+// up holding, `mine_round` says which (plane = mine_round * SPL + sub)
+template <int NV, int LPS, int V4, bool REF_HELD>
+__device__ __forceinline__ float sweep_rounds(const float *const (&vbase)[NV], const int (&offb)[NV],
+                                              int sub, int part, unsigned part_bytes,
+                                              const float2v (&ref)[2 * V4], int &mine_round) {
+    constexpr int SPL = WAVE / LPS;
+    float mine = 0.0f;
+    // The LPS partial sums of a plane are folded across its lanes with DPP adds (no LDS
+    // permutes).
+    if (LPS == 8 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS) {
+        // two rounds of loads in flight while the view count leaves registers for it, and
+        // their two reductions transposed: "odd" lanes fold round 2t+1, the others round
+        // 2t, so the xor-1 step serves both rounds at once.  The last step, lane i with
+        // 7-i, is the only 8-lane exchange DPP has on gfx9; it flips the lane parity, so
+        // "odd" is flipped in the upper quad to meet it.
+        const bool odd = (part ^ (part >> 2)) & 1;
+        mine_round = (part & ~1) | (int)odd;
+        for (int t = 0; t < LPS / 2; t++) {
+            const float a0 = sweep_round<NV, V4, REF_HELD>(vbase, offb, (2 * t) * SPL + sub, part_bytes, ref);
+            const float a1 = sweep_round<NV, V4, REF_HELD>(vbase, offb, (2 * t + 1) * SPL + sub, part_bytes, ref);
+            const float stay = odd ? a1 : a0, moved = odd ? a0 : a1;
+            float r;
+            RN_ADD_DPP(r, moved, stay, RN_DPP_XOR1);
+            RN_ADD_DPP(r, r, r, RN_DPP_XOR2);
+            RN_ADD_DPP(r, r, r, RN_DPP_MIRROR8);
+            if ((part >> 1) == t) mine = r;
+        }
+    } else {
+        static_assert(LPS <= 8, "sweep_coop folds at most 8 lanes per plane");
+        mine_round = part;
+        for (int it = 0; it < LPS; it++) {
+            float acc = sweep_round<NV, V4, REF_HELD>(vbase, offb, it * SPL + sub, part_bytes, ref);
+            if (LPS >= 2) RN_ADD_DPP(acc, acc, acc, RN_DPP_XOR1);
+            if (LPS >= 4) RN_ADD_DPP(acc, acc, acc, RN_DPP_XOR2);
+            if (LPS >= 8) RN_ADD_DPP(acc, acc, acc, RN_DPP_MIRROR8);
+            if (part == it) mine = acc;
+        }
+    }
+    return mine;
+}
+
 template <int NV, int LPS, bool FAST = false>
 __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &fv,
                                            const float *const *__restrict__ tbl,
@@ -360,39 +410,31 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             for (int v = 0; v < NV; v++)
                 offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, P + 12 * v, point, pad_shift);
         }
-        float mine = 0.0f;
-        int mine_round;         // which load round's plane this lane ends up holding
-        // The LPS partial sums of a plane are folded across its lanes with DPP adds (no LDS
-        // permutes).
-        if (LPS == 8 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS) {
-            // two rounds of loads in flight while the view count leaves registers for it, and
-            // their two reductions transposed: "odd" lanes fold round 2t+1, the others round
-            // 2t, so the xor-1 step serves both rounds at once.  The last step, lane i with
-            // 7-i, is the only 8-lane exchange DPP has on gfx9; it flips the lane parity, so
-            // "odd" is flipped in the upper quad to meet it.
-            const bool odd = (part ^ (part >> 2)) & 1;
-            mine_round = (part & ~1) | (int)odd;
-            for (int t = 0; t < LPS / 2; t++) {
-                const float a0 = sweep_round<NV, V4>(vbase, offb, (2 * t) * SPL + sub, part_bytes);
-                const float a1 = sweep_round<NV, V4>(vbase, offb, (2 * t + 1) * SPL + sub, part_bytes);
-                const float stay = odd ? a1 : a0, moved = odd ? a0 : a1;
-                float r;
-                RN_ADD_DPP(r, moved, stay, RN_DPP_XOR1);
-                RN_ADD_DPP(r, r, r, RN_DPP_XOR2);
-                RN_ADD_DPP(r, r, r, RN_DPP_MIRROR8);
-                if ((part >> 1) == t) mine = r;
-            }
-        } else {
-            static_assert(LPS <= 8, "sweep_coop folds at most 8 lanes per plane");
-            mine_round = part;
-            for (int it = 0; it < LPS; it++) {
-                float acc = sweep_round<NV, V4>(vbase, offb, it * SPL + sub, part_bytes);
-                if (LPS >= 2) RN_ADD_DPP(acc, acc, acc, RN_DPP_XOR1);
-                if (LPS >= 4) RN_ADD_DPP(acc, acc, acc, RN_DPP_XOR2);
-                if (LPS >= 8) RN_ADD_DPP(acc, acc, acc, RN_DPP_MIRROR8);
-                if (part == it) mine = acc;
+        // View 0 is the reference image itself: every plane of the ray projects onto the
+        // ray's own pixel there (up to the rounding of the projection, which is checked, not
+        // assumed), so its feature vector is fetched once per chunk instead of once per load
+        // round -- a fifth of the sweep's gathers at 5 views.
+        const int off0 = __builtin_amdgcn_readfirstlane(offb[0]);
+        const bool ref_held = __all(offb[0] == off0);
+        float2v ref[2 * V4];
+#pragma unroll
+        for (int c = 0; c < 2 * V4; c++) ref[c] = float2v{0.f, 0.f};
+        if (ref_held) {
+            typedef const __attribute__((address_space(1))) char *gptr;
+            typedef const __attribute__((address_space(1))) float4v *gptr4;
+#pragma unroll
+            for (int q = 0; q < V4; q++) {
+                const float4v f = *(gptr4)((gptr)vbase[0] + (unsigned)off0 + part_bytes + 16u * q);
+                ref[2 * q] = float2v{f.x, f.y};
+                ref[2 * q + 1] = float2v{f.z, f.w};
             }
         }
+        float mine = 0.0f;
+        int mine_round;         // which load round's plane this lane ends up holding
+        if (ref_held)
+            mine = sweep_rounds<NV, LPS, V4, true>(vbase, offb, sub, part, part_bytes, ref, mine_round);
+        else
+            mine = sweep_rounds<NV, LPS, V4, false>(vbase, offb, sub, part, part_bytes, ref, mine_round);
         const int k = base + mine_round * SPL + sub;
         // FAST (resident path): a constant factor of the softmax's input, value-only
         if (k < p.D) Sl[k] = FAST ? mine * (1.0f / pairs) : mine / pairs;

@@ -200,13 +200,13 @@ __device__ unsigned long long g_phase[16];
 #endif
 // waves per SIMD the register allocation has to leave room for: 7 (<= 72 VGPRs; the kernel
 // needs 74 unconstrained) measured -1.8 % on the 5-view sweep, 8 (64 VGPRs) -0.5 %; the
-// wide sweeps (two load rounds of 7+ views do not fit) and the reference-layout variants
-// (which would spill) are left alone
+// wide sweeps (two load rounds of 7+ views do not fit), the reference-layout variants and
+// the 4-view sweep (which would spill) are left alone
 #ifndef RN_SWEEP_MIN_WAVES
 #define RN_SWEEP_MIN_WAVES 7
 #endif
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
-__global__ __launch_bounds__(BLOCK, (SIM == 2 && MAPMODE == 2 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
+__global__ __launch_bounds__(BLOCK, (SIM == 2 && MAPMODE == 2 && NV >= 5 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
 void k_sweep_map(
     Params p, int n, const int32_t *__restrict__ ray_idxs, FeatureViews fv,
     const float *__restrict__ P, const float *__restrict__ P_inv, const float *__restrict__ cc,
