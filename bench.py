@@ -19,9 +19,12 @@ Prints ONE JSON line on rank 0.  Extra objects:
   roofline     dominant kernel family: algorithmic bytes of its
                launches in the timed region / their hipEvent durations (per launch, on
                the launch stream, via rn_prof_begin/rn_prof_end), vs the 8 TB/s HBM peak
-  cpu_baseline the C oracle's fused K1/K2 path (a port of the reference's algorithm,
-               OpenMP over rays) on a bounded ray sample of the same scene, on this
-               box's host cores
+  cpu_baseline two legs on bounded ray samples of the same scene (rays of all reference
+               images), on this box's host cores: "port" = the C oracle's fused K1/K2 path
+               (the reference's algorithm, OpenMP over rays, all cores) -- also the object's
+               top-level value; "numpy_restatement" = the reference's own NumPy
+               implementation of the MRF stages (mrf/mrf_np.py semantics restated in
+               oracle/cpu_reference.py, per-ray Python loop, one process)
 """
 import argparse
 import json
@@ -181,16 +184,23 @@ def main():
     if dominant:
         d = fam[dominant]
         achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
-        traffic = None
+        # HBM-side bytes per launch come from PMC counters, which need their own rocprofv3
+        # passes (tools/pmc_passes.sh): the figure is read from the summary committed for
+        # this configuration, never measured inside this run -- traffic_source says so
+        traffic = traffic_source = None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if world == 1 and os.path.exists(tpath):     # measured at N=1 launch sizes
             try:
-                traffic = json.load(open(tpath)).get(dominant)
+                tj = json.load(open(tpath))
+                if tj.get("_config", "config2") == args.config:
+                    traffic = tj.get(dominant)
+                    traffic_source = "profiles/pmc_traffic.json (%s): separate rocprofv3 --pmc " \
+                                     "passes of this command, not this run" % tj.get("_profile", "r01_j")
             except Exception:
                 traffic = None
         roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 1),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=traffic,
+                        traffic=traffic, traffic_source=traffic_source,
                         avg_launch_ms=round(d["ms"] / d["launches"], 4), launches=d["launches"],
                         algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]))
     kernels = {k: dict(total_ms_per_step=round(v["ms"] / args.steps, 3),
@@ -199,42 +209,76 @@ def main():
                        if v["ms"] > 0 and v["bytes"] else None)
                for k, v in sorted(fam.items())}
 
-    # ---- CPU baseline: the oracle's fused path on a bounded ray sample ----------------
+    # ---- CPU baseline, two legs on bounded ray samples drawn from ALL reference images -------
+    #  port              the C oracle's fused K1 / K2 (whole path, OpenMP over rays, all cores)
+    #  numpy_restatement oracle/cpu_reference.py = the reference's own CPU implementation
+    #                    (mrf/mrf_np.py: per-ray Python loop, one process) of the stages it
+    #                    has one for -- the 3 BP sweeps + the depth sweep; the plane sweep has
+    #                    no NumPy twin in the reference, its inputs come from the port
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle
+        from oracle import cpu_reference, oracle
         threads = oracle.Oracle.max_threads()
         o = oracle.Oracle(M=cfg["M"], D=cfg["D"], N=gp.neighbors + 1, F=cfg["F"], H=H, W=W,
                           padding=cfg["padding"], bbox=scene.bbox.ravel(), grid_shape=cfg["grid"],
                           threads=threads)
         vg = oracle.voxel_grid_centers(scene.bbox.ravel(), cfg["grid"])
-        views = scene.view_indices_with_neighbors(0, gp.neighbors)
-        feats = bank.stacked(views).cpu().numpy()
-        P = np.array([scene.get_image(v).camera.P for v in views], np.float32)
-        Pi = scene.get_image(0).camera.P_pinv.astype(np.float32)
-        cc = scene.get_image(0).camera.center.ravel().astype(np.float32)
+        cams = []
+        for r in range(V):
+            views = scene.view_indices_with_neighbors(r, gp.neighbors)
+            cams.append((bank.stacked(views).cpu().numpy(),
+                         np.array([scene.get_image(v).camera.P for v in views], np.float32),
+                         scene.get_image(r).camera.P_pinv.astype(np.float32),
+                         scene.get_image(r).camera.center.ravel().astype(np.float32)))
         rng = np.random.default_rng(0)
 
-        def cpu_run(n):
-            ridx = np.sort(rng.choice(H * W, n, replace=False)).astype(np.int32)
+        def cpu_run(n, keep=False):
+            """n rays per reference image, the schedule of forward_pass.py:593-736."""
+            ridx = [np.sort(rng.choice(H * W, n, replace=False)).astype(np.int32) for _ in cams]
             acc = o.prior(0.05)
-            msgs = np.zeros((n, cfg["M"]), np.float32)
+            msgs = [np.zeros((n, cfg["M"]), np.float32) for _ in cams]
+            kept = None
             t = time.perf_counter()
-            for it in range(3):                      # forward_pass.py:593-678
+            for it in range(3):
                 out = o.prior(0.05)
-                o.fused_bp(ridx, feats, P, Pi, cc, vg, acc, msgs, out)
+                for k, (f, P, Pi, cc) in enumerate(cams):
+                    kept_k = o.fused_bp(ridx[k], f, P, Pi, cc, vg, acc, msgs[k], out)
+                    if keep and it == 0:
+                        kept = (kept or []) + [kept_k]
                 acc = out
-            o.fused_depth(ridx, feats, P, Pi, cc, vg, acc, msgs)      # :682-736
-            return time.perf_counter() - t
+            for k, (f, P, Pi, cc) in enumerate(cams):
+                o.fused_depth(ridx[k], f, P, Pi, cc, vg, acc, msgs[k])
+            return time.perf_counter() - t, kept
 
-        probe = min(2000, H * W)
-        tp = cpu_run(probe)
-        n = int(min(H * W, max(probe, probe * args.cpu_seconds / max(tp, 1e-6))))
-        tc = cpu_run(n)
-        cpu = dict(value=round(n / tc, 1), unit="rays/s", cores=threads, kind="port",
-                   sample="%d rays of reference image 0 (of %d per step), 3 BP sweeps + depth "
-                          "sweep with the oracle's fused K1/K2 (oracle/raynet_oracle.c, OpenMP), "
-                          "%.1f s" % (n, rays_per_step, tc))
+        probe = min(400, H * W)
+        tp, _ = cpu_run(probe)
+        n = int(min(H * W, max(probe, probe * 0.6 * args.cpu_seconds / max(tp, 1e-6))))
+        tc, _ = cpu_run(n)
+        port = dict(value=round(V * n / tc, 1), unit="rays/s", cores=threads, kind="port",
+                    sample="%d rays of each of the %d reference images (of %d per step), 3 BP "
+                           "sweeps + depth sweep with the oracle's fused K1/K2 "
+                           "(oracle/raynet_oracle.c, OpenMP), %.1f s" % (n, V, rays_per_step, tc))
+        # NumPy leg: ~70-110 us per ray and sweep, single process
+        n_np = max(50, int(0.4 * args.cpu_seconds / (4 * 100e-6) / V))
+        _, kept = cpu_run(n_np, keep=True)
+        rvi = np.concatenate([k[0] for k in kept])
+        rvc = np.concatenate([k[1] for k in kept])
+        Sv = np.concatenate([k[2] for k in kept])
+        t = time.perf_counter()
+        m_np = np.zeros_like(Sv)
+        acc_np, m_np = cpu_reference.belief_propagation(Sv, rvi, rvc, m_np, cfg["grid"],
+                                                        gamma=0.05, bp_iterations=3)
+        cpu_reference.compute_depth_distribution(Sv, rvi, rvc, m_np, acc_np)
+        tn = time.perf_counter() - t
+        numpy_leg = dict(value=round(len(rvc) / tn, 1), unit="rays/s", cores=1,
+                         kind="numpy_restatement",
+                         sample="%d rays of each of the %d reference images; the reference's "
+                                "NumPy path (mrf/mrf_np.py semantics, oracle/cpu_reference.py: "
+                                "per-ray Python loop, float64 cumulative sums) for the stages it "
+                                "covers -- 3 BP sweeps + depth sweep on the mapped columns; the "
+                                "plane sweep has no NumPy twin in the reference -- %.1f s"
+                                % (n_np, V, tn))
+        cpu = dict(port, legs={"port": port, "numpy_restatement": numpy_leg})
 
     feat_per_ray = 4.0 * (gp.neighbors + 1) * cfg["F"] * (H + cfg["padding"] + 1) * \
         (W + cfg["padding"] + 1) / (H * W)

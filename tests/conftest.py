@@ -33,3 +33,16 @@ def oracle_mod():
     from oracle import oracle
     oracle.build()
     return oracle
+
+
+def assert_depth_flips_are_near_ties(depth, depth_ref, S_new_ref, tie, what=""):
+    """Arg-max depth maps are discontinuous: a depth may differ from the reference's by more
+    than 1e-4 ONLY where the reference's two best probabilities are within `tie` of each
+    other (a near-tie that a last-bit difference decides).  Returns the number of such
+    pixels.  depth, depth_ref: [n]; S_new_ref: [n, M] final distributions of the reference."""
+    flips = np.where(np.abs(np.asarray(depth).ravel() - np.asarray(depth_ref).ravel()) > 1e-4)[0]
+    for r in flips:
+        top = np.sort(S_new_ref[r])[::-1]
+        assert top[0] - top[1] <= tie, "%s ray %d: depth differs away from a near-tie (%g vs %g)" % (
+            what, r, top[0], top[1])
+    return len(flips)

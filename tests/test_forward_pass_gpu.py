@@ -433,13 +433,35 @@ def test_full_size_parity_with_the_oracle(torch, oracle_mod):
         acc, msgs = run_oracle()
         assert np.isfinite(acc).all()
         assert np.abs(acc_hip - acc).max() < 2e-5 * np.abs(acc).max()
+        inherited = 0
         for r in (0, 1):
             f, P, Pi, c = cams[r]
-            _, _, S_new, depth = o.fused_depth(ridx, f, P, Pi, c, vg, acc, msgs[r])
-            d = np.abs(depth.reshape(W, H).T - depth_hip[r])
-            # north star: depth maps within 1e-4 of the reference; what is left are arg-max
-            # near-ties (a 1-ulp change picks the neighbouring voxel)
+            rvi_o, rvc_o, S_new, depth = o.fused_depth(ridx, f, P, Pi, c, vg, acc, msgs[r])
+            d = np.abs(depth - depth_hip[r].T.ravel())
+            # north star: depth maps within 1e-4 of the reference.  A pixel may differ only
+            #  (a) at an arg-max near-tie of the reference (two best probabilities within 5e-5:
+            #      a last-bit change picks the neighbouring voxel), or
+            #  (b) where the difference is INHERITED from the accumulator: hundreds of messages
+            #      of either sign are summed per voxel in a different order (atomics here, the
+            #      oracle's loop there), their fp32 rounding (asserted above: 2e-5 of the
+            #      largest value) moves sigma(acc - msg) of a voxel whose sum nearly cancels.
+            #      Proof per pixel: the ORACLE's own K2 arithmetic on this run's accumulator
+            #      and this ray's messages picks the voxel the HIP path picked.
+            rows = {int(q): k for k, q in enumerate(fp.ray_index[r].cpu().numpy())}
+            for idx in np.where(d > 1e-4)[0]:
+                top = np.sort(S_new[idx])[::-1]
+                if top[0] - top[1] <= 5e-5:
+                    continue
+                m_hip = fp.messages[r][rows[int(idx)]].cpu().numpy()[None]
+                _, _, Sv_o = o.fused_bp(ridx[idx:idx + 1], f, P, Pi, c, vg, acc,
+                                        msgs[r][idx:idx + 1].copy(), o.prior(0.05))
+                again = o.depth_distribution(Sv_o, rvi_o[idx:idx + 1], rvc_o[idx:idx + 1],
+                                             acc_hip, m_hip)
+                d2 = o.depth_from_distribution(again, rvi_o[idx:idx + 1], vg, c)
+                assert abs(float(d2[0]) - float(depth_hip[r].T.ravel()[idx])) <= 1e-4, (r, idx)
+                inherited += 1
             assert (d > 1e-4).sum() <= 20, int((d > 1e-4).sum())
+        assert inherited <= 4, inherited
     finally:
         oracle_mod.Oracle.set_robust_messages(False)
 

@@ -89,8 +89,17 @@ def _logit_close(a, b, ref_msg):
     return bool(np.all(np.abs(a - b) <= tol))
 
 
+@pytest.fixture(params=[False, True], ids=["literal", "robust"])
+def message_form(request, oracle_mod):
+    """Both message forms of the oracle (raynet_oracle.c, g_robust_messages): the literal
+    restatement of mrf_bp.cu:136-167 and the robust one the full-size comparisons use."""
+    oracle_mod.Oracle.set_robust_messages(request.param)
+    yield request.param
+    oracle_mod.Oracle.set_robust_messages(False)
+
+
 @pytest.mark.parametrize("case", sorted(MRF))
-def test_bp_matches_reference_numpy(oracle_mod, case):
+def test_bp_matches_reference_numpy(oracle_mod, case, message_form):
     """Accumulator after each of 3 iterations, messages and final depth
     distribution vs mrf/mrf_np.py:243-385 (float64 cumprod inside, float32
     storage).  Tolerances from SURVEY.md Q8."""

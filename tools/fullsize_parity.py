@@ -22,10 +22,12 @@ scene, bank = make_synthetic_scene(H=H, W=W, n_views=V, focal=1.5 * H)
 gp = GenerationParameters(depth_planes=D, neighbors=4, grid_shape=np.array(grid, np.int32),
                           max_number_of_marched_voxels=M, padding=11, gamma_mrf=0.05)
 res = {}
+fps = {}
 for det in (False, True):
     fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0, deterministic=det)
     depth_hip = np.stack(list(fp.forward_pass(scene, (0, V, 1))))
     res[det] = (depth_hip, fp.accumulator.cpu().numpy())
+    fps[det] = fp
 
 threads = oracle.Oracle.max_threads()
 o = oracle.Oracle(M=M, D=D, N=5, F=32, H=H, W=W, padding=11, bbox=scene.bbox.ravel(),
@@ -62,10 +64,11 @@ for it in range(3):
         f, P, Pi, c = cams[r]
         o.fused_bp(ridx, f, P, Pi, c, vg, acc, msgs[r], out)
     acc = out
-depth_o, dist_o = [], []
+depth_o, dist_o, S_new_o, Sv_o = [], [], {}, {}
 for r in range(V):
     f, P, Pi, c = cams[r]
     _, _, S_new, depth = o.fused_depth(ridx, f, P, Pi, c, vg, acc, msgs[r])
+    S_new_o[r] = S_new
     depth_o.append(depth.reshape(W, H).T)
     top = np.sort(S_new, axis=1)[:, -2:]
     dist_o.append((top[:, 1] - top[:, 0]).reshape(W, H).T)
@@ -88,6 +91,60 @@ for det, (depth_hip, acc_hip) in res.items():
         "of_which_away_from_an_argmax_near_tie(gap>5e-5)": int((bad & (gap > 5e-5)).sum()),
         "depth_max_abs_diff_on_agreeing_pixels": float(d[~bad].max()),
     }
+
+
+def explain(det, r, y, x):
+    """One pixel whose depth differs: the HIP path's final distribution of that ray (K2 on the
+    ray alone, with the run's own accumulator and the ray's own messages) next to the oracle's."""
+    fp = fps[det]
+    ctx = fp._ctx
+    idx = x * H + y
+    row = int((fp.ray_index[r] == idx).nonzero()[0, 0])
+    m_hip = fp.messages[r][row:row + 1].contiguous()
+    f, P, Pi, c = cams[r]
+    d = ctx.dev
+    one = d(np.array([idx], np.int32))
+    rvi = torch.zeros((1, M, 3), dtype=torch.int32, device="cuda")
+    rvc = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    Sv = torch.zeros((1, M), device="cuda")
+    ctx.mvcnn_voxel_space(one, d(f), d(P), d(Pi), d(c), rvi, rvc, Sv)       # K11: mapped column
+    Sv_hip = Sv.cpu().numpy()[0]
+    dist = torch.zeros((1, M), device="cuda")
+    dm = torch.zeros((1,), device="cuda")
+    ctx.fused_depth(one, d(f), d(P), d(Pi), d(c), rvi, rvc, dist, fp.accumulator.contiguous(),
+                    m_hip, dm)
+    dist = dist.cpu().numpy()[0]
+    rvi_o, rvc_o, Sv_or = o.fused_bp(np.array([idx], np.int32), f, P, Pi, c, vg, acc,
+                                     msgs[r][idx:idx + 1].copy(), o.prior(0.05))
+    so = S_new_o[r][idx]
+    cnt = int(rvc_o[0])
+    # the oracle's own K2 arithmetic on the HIP run's state (its accumulator, this ray's
+    # messages): does the difference come from K2, or is it inherited from the accumulator?
+    acc_hip = res[det][1]
+    so_on_hip = o.depth_distribution(Sv_or, rvi_o, rvc_o, acc_hip, m_hip.cpu().numpy())[0]
+    top_o = np.argsort(so)[::-1][:3]
+    top_h = np.argsort(dist)[::-1][:3]
+    return {"image": r, "pixel_yx": [y, x], "voxels_on_ray": cnt,
+            "oracle_top3": [[int(i), float(so[i])] for i in top_o],
+            "hip_top3": [[int(i), float(dist[i])] for i in top_h],
+            "hip_at_oracle_top2": [float(dist[i]) for i in top_o[:2]],
+            "oracle_k2_on_hip_accumulator_and_messages_argmax": int(np.argmax(so_on_hip)),
+            "max_abs_diff_hip_vs_oracle_k2_on_hip_state": float(np.abs(dist[:cnt] - so_on_hip[:cnt]).max()),
+            "max_abs_diff_accumulator_on_ray": float(np.abs(
+                acc_hip[tuple(rvi_o[0, :cnt].T)] - acc[tuple(rvi_o[0, :cnt].T)]).max()),
+            "max_abs_diff_distribution": float(np.abs(dist[:cnt] - so[:cnt]).max()),
+            "max_abs_diff_mapped_column_before_bp": float(np.abs(Sv_hip[:cnt] - Sv_or[0, :cnt]).max()),
+            "max_abs_diff_messages": float(np.abs(m_hip.cpu().numpy()[0, :cnt] - msgs[r][idx, :cnt]).max()),
+            "max_abs_message": float(np.abs(msgs[r][idx, :cnt]).max()),
+            "acc_range_on_ray": [float(acc[tuple(np.asarray(rvi.cpu().numpy()[0, :cnt]).T)].min()),
+                                 float(acc[tuple(np.asarray(rvi.cpu().numpy()[0, :cnt]).T)].max())]}
+
+
+for det, (depth_hip, acc_hip) in res.items():
+    d = np.abs(depth_hip - depth_o)
+    key = "deterministic" if det else "default"
+    report[key]["differing_pixels"] = [explain(det, int(r), int(y), int(x))
+                                       for r, y, x in zip(*np.nonzero(d > 1e-4))]
 print(json.dumps(report, indent=1))
 out = os.path.join(REPO, "gpurun_out", "fullsize_parity.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
