@@ -200,6 +200,14 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
                          const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
                          float *Sr, float *ray_segments, void *stream);
 
+/* Voxel counts only (the traversal of rn_scene_prepare_all without its lists): rvc
+ * [n_images][n] i32, row g*n + i = number of voxels ray ray_idxs[i] crosses in reference image
+ * g (<= M).  The multi-GPU driver balances its ray shards by these counts (the cost of the BP
+ * sweep, the scatter and the depth sweep is per traversed voxel, ray_tracing.pyx:64-199 decides
+ * how many there are); cameras as in rn_scene_prepare_all. */
+int rn_scene_count_voxels(rn_ctx *ctx, int32_t n_images, int32_t n, const int32_t *ray_idxs,
+                          const float *cameras, int32_t *rvc, void *stream);
+
 /* Accumulators of the resident path are stored as 4x4x4 bricks,
  * [ceil(gx/4)][ceil(gy/4)][ceil(gz/4)][4][4][4] f32 = rn_acc_size() floats (a ray stays
  * inside a brick for ~4 steps, so a wavefront's gather touches ~4x fewer cache lines than in

@@ -83,6 +83,7 @@ SIGNATURES = {
     "rn_fused_depth": [_P, _I] + [_P] * 12,
     "rn_scene_prepare": [_P, _I, _P, ctypes.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "rn_scene_prepare_all": [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rn_scene_count_voxels": [_P, _I, _I, _P, _P, _P, _P],
     "rn_acc_copies": [_P],
     "rn_scatter_reset": [_P],
     "rn_acc_size": [_P],

@@ -384,20 +384,19 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     const char *bs = getenv("RAYNET_HIP_BOX_LEVEL");      // A/B knob: start at this tile shape
     ctx->box_level = ctx->box_level0 = bs ? max(0, min(2, atoi(bs))) : 0;
     ctx->box_pin = getenv("RAYNET_HIP_BOX_PIN") != nullptr;
+    if (sweep_lds(p) > 160 * 1024) {      // before anything is allocated
+        delete ctx;
+        return RN_ERR_INVALID;
+    }
     if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
         hipMalloc(&ctx->box_stats, 2 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc(&ctx->box_stats_host, 2 * sizeof(unsigned)) != hipSuccess ||
         hipMemset(ctx->box_stats, 0, 2 * sizeof(unsigned)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
-        delete ctx;
+        rn_destroy(ctx);                  // frees whatever was created (all null-checked)
         return RN_ERR_HIP;
     }
     ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
-    if (sweep_lds(p) > 160 * 1024) {
-        hipFree(ctx->axes);
-        delete ctx;
-        return RN_ERR_INVALID;
-    }
     *out = ctx;
     return RN_OK;
 }
@@ -408,8 +407,8 @@ void rn_destroy(rn_ctx *ctx) {
     if (ctx->axes) hipFree(ctx->axes);
     if (ctx->box_stats) hipFree(ctx->box_stats);
     if (ctx->box_stats_host) hipHostFree(ctx->box_stats_host);
-    hipEventDestroy(ctx->ev0);
-    hipEventDestroy(ctx->ev1);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 2 * ctx->prof_cap; i++) hipEventDestroy(ctx->prof_ev[i]);
     delete[] ctx->prof_ev;
     delete[] ctx->prof_id;
@@ -743,6 +742,22 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
     a.n_images = n_images;
     a.seg = ray_segments;
     launch_sweep<2, true>(ctx, a, true, S(stream));
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_scene_count_voxels(rn_ctx *ctx, int32_t n_images, int32_t n, const int32_t *ray_idxs,
+                          const float *cameras, int32_t *rvc, void *stream) {
+    if (!ctx || n_images < 1 || n < 0 || !ray_idxs || !cameras || !rvc)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (n == 0) return RN_OK;
+    const int N = ctx->p.N;
+    const int cam_stride = 12 * N + 12 + 4;
+    ProfScope prof(ctx, RN_K_TRAVERSE, n * n_images, S(stream));
+    hipLaunchKernelGGL((k_traverse<true>), dim3((n + WAVE - 1) / WAVE, n_images), dim3(WAVE), 0,
+                       S(stream), ctx->p, n, ray_idxs, cameras + 12 * N, cameras + 12 * N + 12,
+                       (const float *)nullptr, (const float *)nullptr, (int32_t *)nullptr, rvc,
+                       cam_stride, (int64_t)n, (float *)nullptr);
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
         const int g = blockIdx.y;
         P_inv += (size_t)g * cam_stride;
         cc += (size_t)g * cam_stride;
-        vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
+        if (vox) vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
         rvc += (size_t)g * rows_per_image;
         if (seg_out) seg_out += (size_t)g * rows_per_image * 8;
     }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
         if (__ballot(active) == 0) break;
         for (int k = 0; k < TRAV_TILE && base + k < p.M; k++) {
             if (active) {
-                tile[lane * (TRAV_TILE + 1) + k] = pack_voxel(cx, cy, cz);
+                if (vox) tile[lane * (TRAV_TILE + 1) + k] = pack_voxel(cx, cy, cz);
                 count++;
                 // advance (ray_tracing.pyx:166-197)
                 if ((cx == last[0] && cy == last[1] && cz == last[2]) || count >= p.M) {
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                 }
             }
         }
+        if (!vox) continue;          // count-only launch (rn_scene_count_voxels): nothing to flush
         wave_sync();
         // flush: TRAV_TILE consecutive steps of one ray are one contiguous segment
         constexpr int RPI = WAVE / TRAV_TILE;      // rows per instruction
@@ -269,6 +270,10 @@ void k_sweep_map(
     const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
     if (MAPMODE != 0) {
         count = min(uniform(rvc[r]), p.M);
+        // resident path: the column of a ray with <= 1 voxels is never read (such rays send no
+        // message, mrf_np.py:300, and their depth is that of voxel 0): no sweep for the rays
+        // that miss the box (5 % of config 2's)
+        if (MAPMODE == 2 && count <= 1) return;
         if (PACKED) {
             typedef const __attribute__((address_space(1))) void *gptr;
             typedef __attribute__((address_space(3))) void *lptr;

@@ -294,10 +294,8 @@ class RayNetForwardPass(ForwardPass):
         # order, AxB: other patch shapes; A/B knob, results do not depend on it)
         tile = os.environ.get("RAYNET_RAY_TILE", "16x16")
         self.ray_tile = tuple(int(t) for t in tile.split("x")) if "x" in tile else None
-        self._ray_lists = {}
-        self._cam_cache = None
-        self._table_cache = None
-        self._stitch_cache = None
+        self._plan = None          # see _build_plan
+        self.shard_balance = None  # per image: traversed voxels of every rank's shard (world > 1)
         self._side_stream = None
         self.ref_idx = -1
         self._ctx = None
@@ -360,36 +358,20 @@ class RayNetForwardPass(ForwardPass):
             return self._forward_pass_reference(scene, images_range)
         return self._forward_pass_resident(scene, images_range)
 
-    def _forward_pass_resident(self, scene, images_range):
-        start, end, skip = images_range
+    # -- the resident schedule ------------------------------------------------
+    def _build_plan(self, scene, refs, bank, ctx, dist, rank, world):
+        """Everything of a resident pass that depends on the scene's cameras, the image range
+        and the sharding only -- camera table, feature-pointer table, ray lists, the ranks'
+        shard bounds, the HBM buffers -- built once and reused while those stay the same
+        (0.2 ms of host work per pass otherwise; 10 % of a rank's step at 8 GPUs)."""
         gp = self._generation_params
         M = gp.max_number_of_marched_voxels
         H, W = scene.image_shape
-        refs = list(range(start, end, skip))
-        dist, rank, world = _dist()
-
-        bank = self._view_features(scene, refs)
-        F = next(iter(bank.values())).shape[-1]
-        ctx = self._context(scene, F)
         dev = ctx.device
-        bank = {v: f.to(dev, torch.float32).contiguous() for v, f in bank.items()}
-        prior = self._prior()
-        # resident accumulators are flat buffers in the backend's own layout (4x4x4 bricks
-        # on the GPU, include/raynet_hip.h); `self.accumulator` is handed out as [gx][gy][gz]
-        G = ctx.acc_size()
-        copies = ctx.acc_copies()
-        acc_in = torch.full((G,), prior, dtype=torch.float32, device=dev)
-        fixed = self.deterministic and hasattr(ctx, "scene_bp_sweep_fixed")
-        acc_part = (torch.zeros((G,), dtype=torch.int64, device=dev) if fixed else
-                    torch.zeros((copies, G), dtype=torch.float32, device=dev))
-        acc_next = torch.empty((G,), dtype=torch.float32, device=dev)
-
-        # all camera matrices go up in ONE copy before the first launch: a pageable
-        # host->device copy is a stream synchronisation point, and one per image would
-        # drain the GPU between images
         N = gp.neighbors + 1
+        V = len(refs)
         stride = 12 * N + 12 + 4
-        cam_host = np.zeros((len(refs), stride), dtype=np.float32)
+        cam_host = np.zeros((V, stride), dtype=np.float32)
         views_of = {}
         for k, r in enumerate(refs):
             views_of[r] = scene.view_indices_with_neighbors(r, gp.neighbors)
@@ -397,94 +379,228 @@ class RayNetForwardPass(ForwardPass):
             cam_host[k, :12 * N] = P.ravel()
             cam_host[k, 12 * N:12 * N + 12] = P_inv.ravel()
             cam_host[k, 12 * N + 12:] = center
-        key = cam_host.tobytes()
-        if self._cam_cache is None or self._cam_cache[0] != key:
-            # patches are enumerated along the direction of the neighbour views' epipolar
-            # lines (of the first reference image: one list serves the whole scene)
-            rows = bool(refs) and sweep_direction(
-                H, W, [scene.get_image(v) for v in views_of[refs[0]]]) == "rows"
-            self._cam_cache = (key, ctx.dev(cam_host), rows)
-            if hasattr(ctx, "scatter_reset"):
-                ctx.scatter_reset()      # new cameras: the scatter re-learns its tile shape
-        cam_dev, epipolar_rows = self._cam_cache[1], self._cam_cache[2]
-
-        # K1 prefix once per reference image; the per-ray columns of ALL images live in one
-        # scene-wide buffer each (image k owns rows [k*npad, k*npad + n)), so that every BP
-        # iteration and the depth sweep are single launches over the whole scene: with
-        # per-image launches the tail of each launch (and, on 8 GPUs, its fixed cost) adds up
-        V = len(refs)
-        shards = []
-        lists = {}
+        ptrs = tuple(tuple(bank[v].data_ptr() for v in views_of[r]) for r in refs)
         patch_rows = self.ray_tile is not None
+        key = (cam_host.tobytes(), ptrs, tuple(refs), H, W, M, world, rank, self.ray_tile,
+               self.sweep_reorder, self.rays_batch, self.deterministic, str(dev),
+               os.environ.get("RAYNET_TILE_ALONG", "auto"), os.environ.get("RAYNET_SHARD", "voxels"))
+        plan = self._plan
+        if plan is not None and plan["key"] == key and not self._filter_out_rays:
+            return plan
+        # all camera matrices go up in ONE copy: a pageable host->device copy is a stream
+        # synchronisation point, one per image would drain the GPU between images
+        cam_dev = ctx.dev(cam_host)
+        if hasattr(ctx, "scatter_reset"):
+            ctx.scatter_reset()          # new cameras: the scatter re-learns its tile shape
+        # patches are enumerated along the direction of the neighbour views' epipolar lines (of
+        # the first reference image: one list serves the whole scene)
+        epipolar_rows = V > 0 and sweep_direction(
+            H, W, [scene.get_image(v) for v in views_of[refs[0]]]) == "rows"
         along = os.environ.get("RAYNET_TILE_ALONG", "auto")
-        along_rows = patch_rows and bool(refs) and (
-            along == "rows" or (along == "auto" and epipolar_rows))
+        along_rows = patch_rows and V > 0 and (along == "rows" or (along == "auto" and epipolar_rows))
+
+        # ---- the images' ray lists in ROW order (what row i of an image's buffers holds)
+        lists = {}
+        shared = None
         for k, r in enumerate(refs):
-            # the image's ray list in ROW order (what row i of its buffers holds)
             if self._filter_out_rays:
                 rays = ctx.dev(np.ascontiguousarray(
                     self.get_valid_rays_per_image(scene, r).astype(np.int32)))
                 if patch_rows:
                     rays = tile_order(rays, H, W, *self.ray_tile, along_rows=along_rows)
             else:       # all H*W rays (forward_pass.py:166-168): built on the device, once
-                key = (H, W, self.ray_tile, along_rows, str(dev))
-                if key not in self._ray_lists:
-                    rays = torch.arange(H * W, dtype=torch.int32, device=dev)
+                if shared is None:
+                    shared = torch.arange(H * W, dtype=torch.int32, device=dev)
                     if patch_rows:
-                        rays = tile_order(rays, H, W, *self.ray_tile, along_rows=along_rows)
-                    self._ray_lists[key] = rays
-                rays = self._ray_lists[key]
-            total = len(rays)
-            lo, hi = shard_bounds(total, rank, world)
+                        shared = tile_order(shared, H, W, *self.ray_tile, along_rows=along_rows)
+                rays = shared
             lists[r] = rays
-            shards.append((rays[lo:hi], lo, hi, total))
+
+        # ---- shard bounds: bounds[k][q] .. bounds[k][q+1] = rows of image k owned by rank q
+        bounds = [[shard_bounds(len(lists[r]), q, world)[0] for q in range(world)] +
+                  [len(lists[r])] for r in refs]
+        balance = None
+        if world > 1 and V > 0 and os.environ.get("RAYNET_SHARD", "voxels") == "voxels" and \
+                hasattr(ctx, "count_voxels"):
+            # equal RAY counts leave the ranks unequal work: the border strips of an image miss
+            # most of the box (config 2: the strips' voxel totals spread 0.1 .. 1.6 x the mean).
+            # The traversal's counts (bit-exact integers, the same on every rank: no exchange)
+            # weigh every ray as `count + alpha`, alpha = the plane sweep's per-ray cost in
+            # voxel units; cuts fall on whole 256-row scatter tiles.
+            # Images that share one ray list get the SAME cuts (their traversal / sweep is one
+            # launch over all of them, and so is every later kernel: only a rank's total
+            # counts), from the weights summed over the images.
+            alpha = float(os.environ.get("RAYNET_SHARD_ALPHA", "0.6"))
+
+            def cut(c):
+                """c: int64 [n] voxel counts per row -> world + 1 row bounds of equal weight"""
+                n_k = int(c.numel())
+                if n_k == 0:
+                    return [0] * (world + 1)
+                # integer weights: their prefix sums are exact whatever the scan order, so
+                # every rank computes the same cuts from the same (bit-exact) counts
+                extra = int(round(16 * alpha * int(c.sum().item()) / n_k))
+                w = torch.cumsum(c * 16 + extra, 0)
+                total_w = int(w[-1].item())
+                targets = torch.tensor([total_w * q // world for q in range(1, world)],
+                                       dtype=torch.int64, device=w.device)
+                b = torch.searchsorted(w, targets).cpu().tolist()
+                # whole 256-row scatter tiles where the image is large enough for that to
+                # leave the balance intact, finer otherwise
+                align = 256
+                while align > 1 and align * 4 * world > n_k:
+                    align //= 2
+                cuts = [0]
+                for v in b:
+                    cuts.append(max(cuts[-1], min(n_k, (int(v) + align // 2) // align * align)))
+                return cuts + [n_k]
+
+            def shares(c, cuts):
+                cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=c.device),
+                                torch.cumsum(c, 0)]).cpu()
+                return [int(cs[cuts[q + 1]] - cs[cuts[q]]) for q in range(world)]
+
+            if shared is not None:
+                counts = ctx.count_voxels(shared, cam_dev).to(torch.int64)      # [V, n]
+                cuts = cut(counts.sum(0))
+                bounds = [cuts for _ in refs]
+                balance = [shares(counts[k], cuts) for k in range(V)]
+            else:
+                bounds, balance = [], []
+                for k, r in enumerate(refs):
+                    c = ctx.count_voxels(lists[r], cam_dev[k:k + 1])[0].to(torch.int64)
+                    bounds.append(cut(c))
+                    balance.append(shares(c, bounds[-1]))
+            if dist is not None:         # belt and braces: the ranks must agree on the cuts
+                t = torch.tensor(bounds, dtype=torch.int64, device=dev)
+                lo_t, hi_t = t.clone(), t.clone()
+                dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+                assert torch.equal(lo_t, hi_t), "ranks disagree on the shard bounds"
+        shards = []
+        for k, r in enumerate(refs):
+            lo, hi = bounds[k][rank], bounds[k][rank + 1]
+            shards.append((lists[r][lo:hi], lo, hi, len(lists[r])))
         # rows per image: the largest shard ANY rank holds (the same number on every rank, the
         # depth maps are exchanged with an all-gather), rounded to whole scatter tiles
-        npad = max([(sh[3] + world - 1) // world for sh in shards] + [1])
+        npad = max([bounds[k][q + 1] - bounds[k][q] for k in range(V) for q in range(world)] + [1])
         npad = (npad + 255) // 256 * 256            # scatter tiles never straddle two images
-        vox_all = torch.empty((V * npad, M), dtype=torch.int32, device=dev)
-        Sr_all = torch.empty((V * npad, M), dtype=torch.float32, device=dev)
-        msgs_all = torch.empty((V * npad, M), dtype=torch.float32, device=dev)   # see _Messages
-        rvc_all = torch.zeros((V * npad,), dtype=torch.int32, device=dev)   # padding rays: count 0
+
+        # ---- HBM: messages and counts of ALL images stay resident (they carry state across
+        # the iterations); the voxel lists and columns of as many images as fit -- the rest are
+        # recomputed group by group in every sweep, like the reference recomputes everything
+        G = ctx.acc_size()
+        per_image = npad * M * 4
+        budget = float(os.environ.get("RAYNET_RESIDENT_GB", "0")) * 2 ** 30
+        if budget <= 0 and dev.type == "cuda":
+            free, _ = torch.cuda.mem_get_info(dev)
+            if plan is not None:                     # the outgoing plan's buffers are reusable
+                free += plan["bytes"]
+            budget = 0.9 * free
+        fixed = V * per_image + 3 * G * 8 + V * npad * 48
+        if budget > 0 and fixed + 2 * per_image > budget:
+            raise MemoryError(
+                "resident schedule: the messages of %d reference images (%.1f GB) do not leave "
+                "room for one image's columns in %.1f GB of HBM; run fewer images per call"
+                % (V, V * per_image / 2 ** 30, budget / 2 ** 30))
+        Vg = V if budget <= 0 else int(max(1, min(V, (budget - fixed) // (2 * per_image))))
+        groups = [list(range(g, min(g + Vg, V))) for g in range(0, V, Vg)] if V else []
+        self._plan = plan = None                     # release the old buffers first
+        rows_g = Vg * npad
+        fixed_pt = self.deterministic and hasattr(ctx, "scene_bp_sweep_fixed")
+        plan = dict(
+            key=key, cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
+            balance=balance, shards=shards, npad=npad, groups=groups, Vg=Vg, shared=shared,
+            patch_rows=patch_rows, fixed=fixed_pt,
+            table=torch.tensor(ptrs, dtype=torch.int64).to(dev) if V else None,
+            vox=torch.empty((rows_g, M), dtype=torch.int32, device=dev),
+            Sr=torch.empty((rows_g, M), dtype=torch.float32, device=dev),
+            msgs=torch.empty((V * npad, M), dtype=torch.float32, device=dev),   # see _Messages
+            rvc=torch.zeros((V * npad,), dtype=torch.int32, device=dev),   # padding rays: count 0
+            depth=torch.zeros((V * npad,), dtype=torch.float32, device=dev),
+            acc_a=torch.empty((G,), dtype=torch.float32, device=dev),
+            acc_b=torch.empty((G,), dtype=torch.float32, device=dev),
+            acc_part=(torch.zeros((G,), dtype=torch.int64, device=dev) if fixed_pt else
+                      torch.zeros((ctx.acc_copies(), G), dtype=torch.float32, device=dev)),
+            bytes=fixed + 2 * rows_g * M * 4, orders={}, stitch=None)
+        if not self._filter_out_rays:
+            self._plan = plan
+        return plan
+
+    def _forward_pass_resident(self, scene, images_range):
+        start, end, skip = images_range
+        gp = self._generation_params
+        H, W = scene.image_shape
+        refs = list(range(start, end, skip))
+        dist, rank, world = _dist()
+        # an initialised process group runs its collectives even when it has ONE rank (that is
+        # how a single-GPU box exercises the RCCL path); no group, no collectives
+        collective = dist is not None
+
+        bank = self._view_features(scene, refs)
+        F = next(iter(bank.values())).shape[-1]
+        ctx = self._context(scene, F)
+        dev = ctx.device
+        bank = {v: f.to(dev, torch.float32).contiguous() for v, f in bank.items()}
+        prior = self._prior()
+        N = gp.neighbors + 1
+        V = len(refs)
+        plan = self._build_plan(scene, refs, bank, ctx, dist, rank, world)
+        cam_dev, views_of, lists, shards = plan["cam_dev"], plan["views_of"], plan["lists"], plan["shards"]
+        npad, groups, patch_rows, fixed = plan["npad"], plan["groups"], plan["patch_rows"], plan["fixed"]
+        vox_g, Sr_g, msgs_all, rvc_all = plan["vox"], plan["Sr"], plan["msgs"], plan["rvc"]
+        self.shard_balance = plan["balance"]
+        # resident accumulators are flat buffers in the backend's own layout (4x4x4 bricks
+        # on the GPU, include/raynet_hip.h); `self.accumulator` is handed out as [gx][gy][gz]
+        acc_in, acc_next, acc_part = plan["acc_a"], plan["acc_b"], plan["acc_part"]
+        if self._side_stream is not None:      # an abandoned earlier pass may still be copying
+            torch.cuda.current_stream(dev).wait_stream(self._side_stream)
+        acc_in.fill_(prior)
+        acc_part.zero_()
+        if self.bp_iterations == 0:
+            msgs_all.zero_()          # the depth sweep then reads the initial (zero) messages
+
         per_image = {}
-        orders = {}
         for k, r in enumerate(refs):
             ridx, lo, hi, total = shards[k]
             n = len(ridx)
             row0 = k * npad
             self.ray_index[r] = ridx
-            per_image[r] = dict(ridx=ridx, n=n, lo=lo, hi=hi, total=total, row0=row0,
+            per_image[r] = dict(k=k, ridx=ridx, n=n, lo=lo, hi=hi, total=total, row0=row0,
                                 center=cam_dev[k, 12 * N + 12:],
-                                vox=vox_all[row0:row0 + n], rvc=rvc_all[row0:row0 + n],
-                                Sr=Sr_all[row0:row0 + n], msgs=msgs_all[row0:row0 + n])
+                                rvc=rvc_all[row0:row0 + n], msgs=msgs_all[row0:row0 + n])
 
         def order_for(ridx_slice, lo_i, hi_i, images):
             # patch rows are already compact in both image directions (measured: the
             # row-major schedule gains nothing on top of them)
             if patch_rows or not self.sweep_reorder or sweep_direction(H, W, images) != "rows":
                 return None
-            key = (lo_i, hi_i)
-            if self._filter_out_rays or key not in orders:
-                orders[key] = row_major_order(ridx_slice, H, W)
-            return orders[key]
+            okey = (lo_i, hi_i)
+            if self._filter_out_rays or okey not in plan["orders"]:
+                plan["orders"][okey] = row_major_order(ridx_slice, H, W)
+            return plan["orders"][okey]
 
-        whole = not self._filter_out_rays and not self.rays_batch and V > 0
+        whole = plan["shared"] is not None and not self.rays_batch and V > 0 and \
+            hasattr(ctx, "scene_prepare_all")
         if whole and not patch_rows and self.sweep_reorder:
             # (patch rows take no sweep order at all, see order_for)
             modes = {sweep_direction(H, W, [scene.get_image(v) for v in views_of[r]]) for r in refs}
             whole = len(modes) == 1
-        if whole and hasattr(ctx, "scene_prepare_all"):
-            # every image traverses / sweeps the same ray list: two launches for the scene
-            ridx, lo, hi, total = shards[0]
-            order = order_for(ridx, lo, hi, [scene.get_image(v) for v in views_of[refs[0]]])
-            ptrs = tuple(tuple(bank[v].data_ptr() for v in views_of[r]) for r in refs)
-            if self._table_cache is None or self._table_cache[0] != ptrs:
-                self._table_cache = (ptrs, torch.tensor(ptrs, dtype=torch.int64).to(dev))
-            table = self._table_cache[1]
-            ctx.scene_prepare_all(V, npad, ridx, table, cam_dev, vox_all, rvc_all, Sr_all,
-                                  order=order)
-        else:
-            for k, r in enumerate(refs):
+
+        def prepare(group):
+            """K1 prefix (traversal, plane sweep, mapping, clip + renormalise) of the group's
+            images into the group buffers; image k of the group sits at rows [j*npad, ...)."""
+            g0, g1 = group[0], group[-1] + 1
+            if whole:
+                # every image traverses / sweeps the same ray list: two launches for the group
+                ridx, lo, hi, total = shards[g0]
+                order = order_for(ridx, lo, hi, [scene.get_image(v) for v in views_of[refs[g0]]])
+                ctx.scene_prepare_all(g1 - g0, npad, ridx, plan["table"][g0:g1], cam_dev[g0:g1],
+                                      vox_g[:(g1 - g0) * npad], rvc_all[g0 * npad:g1 * npad],
+                                      Sr_g[:(g1 - g0) * npad], order=order)
+                return
+            for j, k in enumerate(group):
+                r = refs[k]
                 st = per_image[r]
                 ridx, lo, n = st["ridx"], st["lo"], st["n"]
                 views = views_of[r]
@@ -492,40 +608,51 @@ class RayNetForwardPass(ForwardPass):
                 P = cam_dev[k, :12 * N]
                 P_inv = cam_dev[k, 12 * N:12 * N + 12]
                 B = self.rays_batch if self.rays_batch else max(n, 1)
+                vox_k, Sr_k = vox_g[j * npad:j * npad + n], Sr_g[j * npad:j * npad + n]
                 for i in range(0, n, B):
                     order = order_for(ridx[i:i + B], lo + i, min(lo + i + B, st["hi"]), images)
                     ctx.scene_prepare(ridx[i:i + B], [bank[v] for v in views], P, P_inv,
-                                      st["center"], st["vox"][i:i + B], st["rvc"][i:i + B],
-                                      st["Sr"][i:i + B], order=order)
+                                      st["center"], vox_k[i:i + B], st["rvc"][i:i + B],
+                                      Sr_k[i:i + B], order=order)
 
-        n_all = V * npad
-        B_all = self.rays_batch // 256 * 256 if self.rays_batch and self.rays_batch >= 256 else n_all
+        # K1 prefix once per reference image when every image's columns fit in HBM (they do at
+        # every configuration of BASELINE.json); otherwise group by group inside every sweep.
+        # The per-ray columns of a group's images live in one buffer each (image j owns rows
+        # [j*npad, j*npad + n)), so that a BP iteration is ONE launch per kernel over the group
+        one_group = len(groups) <= 1
+        if one_group and groups:
+            prepare(groups[0])
+        sweep = ctx.scene_bp_sweep_fixed if fixed else ctx.scene_bp_sweep
+        combine = ctx.acc_combine_fixed if fixed else ctx.acc_combine
         for it in range(self.bp_iterations):
             # iteration 0 starts from zero messages (forward_pass.py:613-615); with the
             # shipped quirk every iteration does (memmap reopened with mode="w+", Q1)
             first = it == 0 or self.reference_quirks
-            sweep = ctx.scene_bp_sweep_fixed if fixed else ctx.scene_bp_sweep
-            for i in range(0, n_all, B_all):
-                sweep(Sr_all[i:i + B_all], vox_all[i:i + B_all], rvc_all[i:i + B_all], acc_in,
-                      msgs_all[i:i + B_all], acc_part, first_sweep=first, patch_rows=patch_rows,
-                      uniform_acc=it == 0)      # iteration 0: the prior everywhere
-            # swap + prior refill of forward_pass.py:676-678; across ranks the prior is
-            # added once, after the sum
-            if fixed:
-                if world > 1:      # integer sum: the same bits whatever the ring order
-                    dist.all_reduce(acc_part, op=dist.ReduceOp.SUM)
-                ctx.acc_combine_fixed(acc_part, prior, acc_next)
-            else:
-                if world > 1:      # partial sums of all ranks, then the prior once
-                    dist.all_reduce(acc_part, op=dist.ReduceOp.SUM)
-                ctx.acc_combine(acc_part, prior, acc_next)
+            for group in groups:
+                if not one_group:
+                    prepare(group)
+                n_g = len(group) * npad
+                g_row0 = group[0] * npad
+                B_g = self.rays_batch // 256 * 256 if self.rays_batch and self.rays_batch >= 256 else n_g
+                for i in range(0, n_g, B_g):
+                    sweep(Sr_g[i:min(i + B_g, n_g)], vox_g[i:min(i + B_g, n_g)],
+                          rvc_all[g_row0 + i:g_row0 + min(i + B_g, n_g)], acc_in,
+                          msgs_all[g_row0 + i:g_row0 + min(i + B_g, n_g)], acc_part,
+                          first_sweep=first, patch_rows=patch_rows,
+                          uniform_acc=it == 0)      # iteration 0: the prior everywhere
+            # swap + prior refill of forward_pass.py:676-678; across ranks the partial sums are
+            # merged first (integer sums in the deterministic mode: the same bits whatever the
+            # ring order) and the prior is added once, after the sum
+            if collective:
+                dist.all_reduce(acc_part, op=dist.ReduceOp.SUM)
+            combine(acc_part, prior, acc_next)
             acc_in, acc_next = acc_next, acc_in
         self.accumulator = ctx.acc_to_grid(acc_in)
 
         # depth sweep.  One rank: image by image, and while image k+1 is decoded a side stream
         # maps image k's rows to pixels and copies the map to (pinned) host memory -- the
         # reference yields after each image's `.get()`.  Several ranks: one launch over the
-        # scene (each image measures from its own camera centre) and one all-reduce.
+        # group (each image measures from its own camera centre) and one all-gather.
         identity = not patch_rows and not self._filter_out_rays
         cuda = dev.type == "cuda"
 
@@ -542,37 +669,49 @@ class RayNetForwardPass(ForwardPass):
                 done.record()
             return host, done
 
-        depth_all = torch.zeros((n_all,), dtype=torch.float32, device=dev)
+        n_all = V * npad
+        depth_all = plan["depth"]
         pending = []
-        if world == 1:
+        if not collective:
             if cuda and self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=dev)
             side = self._side_stream if cuda else None
             if side is not None:
                 depth_all.record_stream(side)
             last = per_image[refs[-1]] if refs else None
-            for r in refs:
-                st = per_image[r]
-                msgs = st["msgs"]
-                if self.reference_quirks and last["n"] == st["n"]:
-                    msgs = last["msgs"]   # every image decoded with the LAST one's
-                dst = depth_all[st["row0"]:st["row0"] + st["n"]]
-                B = B_all if B_all < n_all else max(st["n"], 1)
-                for i in range(0, st["n"], B):
-                    ctx.scene_depth(st["Sr"][i:i + B], st["vox"][i:i + B], st["rvc"][i:i + B],
-                                    acc_in, msgs[i:i + B], st["center"], None, dst[i:i + B])
-                if side is None:
-                    pending.append((r,) + to_host(dst, r))
-                else:
-                    ready = torch.cuda.Event()
-                    ready.record()
-                    with torch.cuda.stream(side):
-                        side.wait_event(ready)
+            for group in groups:
+                if not one_group:
+                    prepare(group)
+                for j, k in enumerate(group):
+                    r = refs[k]
+                    st = per_image[r]
+                    msgs = st["msgs"]
+                    if self.reference_quirks and last["n"] == st["n"]:
+                        msgs = last["msgs"]   # every image decoded with the LAST one's
+                    dst = depth_all[st["row0"]:st["row0"] + st["n"]]
+                    Sr_k, vox_k = Sr_g[j * npad:j * npad + st["n"]], vox_g[j * npad:j * npad + st["n"]]
+                    B = self.rays_batch // 256 * 256 if self.rays_batch and self.rays_batch >= 256 \
+                        else max(st["n"], 1)
+                    for i in range(0, st["n"], B):
+                        ctx.scene_depth(Sr_k[i:i + B], vox_k[i:i + B], st["rvc"][i:i + B],
+                                        acc_in, msgs[i:i + B], st["center"], None, dst[i:i + B])
+                    if side is None:
                         pending.append((r,) + to_host(dst, r))
+                    else:
+                        ready = torch.cuda.Event()
+                        ready.record()
+                        with torch.cuda.stream(side):
+                            side.wait_event(ready)
+                            pending.append((r,) + to_host(dst, r))
         else:
             centers = cam_dev[:, 12 * N + 12:].contiguous()
-            ctx.scene_depth(Sr_all, vox_all, rvc_all, acc_in, msgs_all, centers, None, depth_all,
-                            rays_per_center=npad)
+            for group in groups:
+                if not one_group:
+                    prepare(group)
+                g0, n_g = group[0], len(group) * npad
+                ctx.scene_depth(Sr_g[:n_g], vox_g[:n_g], rvc_all[g0 * npad:g0 * npad + n_g], acc_in,
+                                msgs_all[g0 * npad:g0 * npad + n_g], centers[g0:g0 + len(group)],
+                                None, depth_all[g0 * npad:g0 * npad + n_g], rays_per_center=npad)
             # ONE all-gather of the ranks' row blocks (each rank sends only its own rows), ONE
             # gather that puts every image's rows of every rank into pixel order (its index
             # map depends on the ray lists and the sharding only: built once), ONE copy to the
@@ -581,20 +720,18 @@ class RayNetForwardPass(ForwardPass):
             flat = torch.empty((world * n_all + 1,), dtype=torch.float32, device=dev)
             flat[-1] = 0.0
             dist.all_gather_into_tensor(flat[:-1], depth_all)
-            skey = (tuple(lists[r].data_ptr() for r in refs), tuple(len(lists[r]) for r in refs),
-                    world, npad, HW, str(dev))
-            if self._filter_out_rays or self._stitch_cache is None or self._stitch_cache[0] != skey:
+            if plan["stitch"] is None:
                 src = torch.full((V * HW,), world * n_all, dtype=torch.int64, device=dev)
                 for k, r in enumerate(refs):
-                    total = per_image[r]["total"]
                     rays = lists[r].long()
+                    cuts = plan["bounds"][k]
                     for q in range(world):
-                        lo_q, hi_q = shard_bounds(total, q, world)
+                        lo_q, hi_q = cuts[q], cuts[q + 1]
                         src[k * HW + rays[lo_q:hi_q]] = (
                             q * n_all + k * npad +
                             torch.arange(hi_q - lo_q, dtype=torch.int64, device=dev))
-                self._stitch_cache = (skey, src, [lists[r] for r in refs])   # (keeps the lists alive)
-            maps = flat.index_select(0, self._stitch_cache[1])
+                plan["stitch"] = src
+            maps = flat.index_select(0, plan["stitch"])
             host = torch.empty((V * HW,), dtype=torch.float32, pin_memory=cuda)
             host.copy_(maps, non_blocking=True)
             done = torch.cuda.Event() if cuda else None

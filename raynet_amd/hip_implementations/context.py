@@ -21,6 +21,28 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _chk(t, dtype, min_numel=0, name="tensor", optional=False):
+    """The C ABI takes raw device pointers: a tensor handed to it must be what the kernels
+    assume -- on the GPU, contiguous, of the stated dtype, at least `min_numel` elements, rows
+    16-byte aligned (the kernels use 128-bit loads) -- or the call fails HERE, not as a silent
+    out-of-bounds access."""
+    if t is None:
+        if optional:
+            return t
+        raise ValueError("%s: required" % name)
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError("%s: expected a CUDA tensor" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s: expected %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s: must be contiguous" % name)
+    if t.numel() < min_numel:
+        raise ValueError("%s: %d elements, need >= %d" % (name, t.numel(), min_numel))
+    if t.numel() and t.data_ptr() % 16:
+        raise ValueError("%s: data pointer is not 16-byte aligned" % name)
+    return t
+
+
 def to_device(x, dtype=None, device="cuda"):
     """The reference's `to_gpu` / all_arrays_to_gpu (cuda_implementations/utils.py:11-22):
     NumPy arrays are uploaded, device tensors pass through untouched."""
@@ -274,59 +296,105 @@ class HipContext(object):
 
     def scene_prepare(self, ray_idxs, feature_views, P, P_inv, center, vox, rvc, Sr, order=None):
         assert len(feature_views) == self.N
-        assert order is None or (order.dtype == torch.int32 and len(order) == len(ray_idxs))
+        n = len(ray_idxs)
+        f32, i32 = torch.float32, torch.int32
+        fdim = self.feature_shape[1] * self.feature_shape[2] * self.F
+        for k, fv in enumerate(feature_views):
+            _chk(fv, f32, fdim, "feature map %d" % k)
+        _chk(ray_idxs, i32, n, "ray_idxs"); _chk(order, i32, n, "order", optional=True)
+        _chk(P, f32, 12 * self.N, "P"); _chk(P_inv, f32, 12, "P_inv"); _chk(center, f32, 3, "center")
+        _chk(vox, i32, n * self.M, "vox"); _chk(rvc, i32, n, "rvc"); _chk(Sr, f32, n * self.M, "Sr")
+        assert order is None or len(order) == n
         arr = (ctypes.c_void_p * self.N)(*[fv.data_ptr() for fv in feature_views])
-        self._check(self.lib.rn_scene_prepare(self._h, len(ray_idxs), _ptr(ray_idxs), arr, _ptr(P),
+        self._check(self.lib.rn_scene_prepare(self._h, n, _ptr(ray_idxs), arr, _ptr(P),
                                               _ptr(P_inv), _ptr(center), _ptr(order), _ptr(vox),
                                               _ptr(rvc), _ptr(Sr),
-                                              _ptr(self._segments(len(ray_idxs))), _stream()))
+                                              _ptr(self._segments(n)), _stream()))
 
     def scene_prepare_all(self, n_images, rows_per_image, ray_idxs, feature_table, cameras, vox,
                           rvc, Sr, order=None):
         """feature_table: int64 CUDA tensor [n_images, N] of device pointers;
         cameras: float32 CUDA tensor [n_images, 12N + 16]."""
-        assert feature_table.dtype == torch.int64 and feature_table.is_contiguous()
+        n, rows = len(ray_idxs), int(n_images) * int(rows_per_image)
+        f32, i32 = torch.float32, torch.int32
+        _chk(feature_table, torch.int64, n_images * self.N, "feature_table")
         assert tuple(feature_table.shape) == (n_images, self.N)
-        assert cameras.dtype == torch.float32 and cameras.is_contiguous()
+        _chk(cameras, f32, n_images * (12 * self.N + 16), "cameras")
         assert tuple(cameras.shape) == (n_images, 12 * self.N + 16)
-        assert order is None or (order.dtype == torch.int32 and len(order) == len(ray_idxs))
+        _chk(ray_idxs, i32, n, "ray_idxs"); _chk(order, i32, n, "order", optional=True)
+        _chk(vox, i32, rows * self.M, "vox"); _chk(rvc, i32, rows, "rvc")
+        _chk(Sr, f32, rows * self.M, "Sr")
+        assert order is None or len(order) == n
         self._check(self.lib.rn_scene_prepare_all(
-            self._h, int(n_images), len(ray_idxs), int(rows_per_image), _ptr(ray_idxs),
+            self._h, int(n_images), n, int(rows_per_image), _ptr(ray_idxs),
             _ptr(feature_table), _ptr(cameras), _ptr(order), _ptr(vox), _ptr(rvc), _ptr(Sr),
-            _ptr(self._segments(int(n_images) * int(rows_per_image))), _stream()))
+            _ptr(self._segments(rows)), _stream()))
+
+    def count_voxels(self, ray_idxs, cameras):
+        """-> int32 [n_images, n]: voxels crossed by every ray of ray_idxs in every reference
+        image (rn_scene_count_voxels; cameras as for scene_prepare_all)."""
+        n_images, n = int(cameras.shape[0]), len(ray_idxs)
+        _chk(cameras, torch.float32, n_images * (12 * self.N + 16), "cameras")
+        _chk(ray_idxs, torch.int32, n, "ray_idxs")
+        out = torch.zeros((n_images, n), dtype=torch.int32, device=self.device)
+        self._check(self.lib.rn_scene_count_voxels(self._h, n_images, n, _ptr(ray_idxs),
+                                                   _ptr(cameras), _ptr(out), _stream()))
+        return out
+
+    def _chk_rows(self, Sr, vox, rvc, msgs, acc, part=None, part_dtype=torch.float32):
+        n = len(rvc)
+        f32, i32 = torch.float32, torch.int32
+        _chk(Sr, f32, n * self.M, "Sr"); _chk(vox, i32, n * self.M, "vox"); _chk(rvc, i32, n, "rvc")
+        _chk(msgs, f32, n * self.M, "msgs"); _chk(acc, f32, self.acc_size(), "accumulator")
+        if part is not None:
+            _chk(part, part_dtype, self.acc_size(), "partial accumulator")
+        return n
 
     def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False,
                        patch_rows=False, uniform_acc=False):
-        self._check(self.lib.rn_scene_bp_sweep(self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc),
+        n = self._chk_rows(Sr, vox, rvc, msgs, acc_in, acc_part)
+        self._check(self.lib.rn_scene_bp_sweep(self._h, n, _ptr(Sr), _ptr(vox), _ptr(rvc),
                                                _ptr(acc_in), _ptr(msgs), _ptr(acc_part),
                                                (1 if first_sweep else 0) | (2 if uniform_acc else 0),
                                                1 if patch_rows else 0, _stream()))
 
     def scene_bp_sweep_fixed(self, Sr, vox, rvc, acc_in, msgs, acc_part_fixed, first_sweep=False,
                              patch_rows=False, uniform_acc=False):
-        assert acc_part_fixed.dtype == torch.int64
+        n = self._chk_rows(Sr, vox, rvc, msgs, acc_in, acc_part_fixed, torch.int64)
         self._check(self.lib.rn_scene_bp_sweep_fixed(
-            self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc), _ptr(acc_in), _ptr(msgs),
+            self._h, n, _ptr(Sr), _ptr(vox), _ptr(rvc), _ptr(acc_in), _ptr(msgs),
             _ptr(acc_part_fixed), (1 if first_sweep else 0) | (2 if uniform_acc else 0),
             1 if patch_rows else 0, _stream()))
 
     def acc_combine_fixed(self, acc_part_fixed, prior, acc_out):
-        assert acc_part_fixed.dtype == torch.int64
+        _chk(acc_part_fixed, torch.int64, self.acc_size(), "partial accumulator")
+        _chk(acc_out, torch.float32, self.acc_size(), "accumulator")
         self._check(self.lib.rn_acc_combine_fixed(self._h, _ptr(acc_part_fixed), float(prior),
                                                   _ptr(acc_out), _stream()))
 
     def acc_combine(self, acc_part, prior, acc_out):
+        _chk(acc_part, torch.float32, self.acc_size(), "partial accumulator")
+        _chk(acc_out, torch.float32, self.acc_size(), "accumulator")
         self._check(self.lib.rn_acc_combine(self._h, _ptr(acc_part), float(prior), _ptr(acc_out),
                                             _stream()))
 
     def acc_reduce_local(self, acc_part, acc_out):
+        _chk(acc_part, torch.float32, self.acc_size(), "partial accumulator")
+        _chk(acc_out, torch.float32, self.acc_size(), "accumulator")
         self._check(self.lib.rn_acc_reduce_local(self._h, _ptr(acc_part), _ptr(acc_out), _stream()))
 
     def acc_add_prior(self, acc, prior):
+        _chk(acc, torch.float32, self.acc_size(), "accumulator")
         self._check(self.lib.rn_acc_add_prior(self._h, _ptr(acc), float(prior), _stream()))
 
     def scene_depth(self, Sr, vox, rvc, acc, msgs, center, S_new, depth_map, rays_per_center=0):
-        self._check(self.lib.rn_scene_depth(self._h, len(rvc), _ptr(Sr), _ptr(vox), _ptr(rvc),
+        n = self._chk_rows(Sr, vox, rvc, msgs, acc)
+        _chk(S_new, torch.float32, n * self.M, "S_new", optional=True)
+        _chk(depth_map, torch.float32, n, "depth_map", optional=True)
+        groups = (n + rays_per_center - 1) // rays_per_center if rays_per_center > 0 else 1
+        _chk(center, torch.float32, 4 * groups if rays_per_center > 0 else 3, "center",
+             optional=depth_map is None)
+        self._check(self.lib.rn_scene_depth(self._h, n, _ptr(Sr), _ptr(vox), _ptr(rvc),
                                             _ptr(acc), _ptr(msgs), _ptr(center),
                                             int(rays_per_center), _ptr(S_new), _ptr(depth_map),
                                             _stream()))

@@ -15,7 +15,7 @@ class OracleBackend(object):
         self.o = oracle.Oracle(M, D, N, F, H, W, padding, bbox, grid_shape)
         self.device = torch.device("cpu")
         self.grid_shape = tuple(int(g) for g in grid_shape)
-        self.M = int(M)
+        self.M, self.N = int(M), int(N)
         self._grid_set = False
         self._vg = None
 
@@ -44,6 +44,16 @@ class OracleBackend(object):
         v = vox.numpy()
         return np.ascontiguousarray(np.stack([v >> 20, (v >> 10) & 1023, v & 1023], axis=-1)
                                     .astype(np.int32))
+
+    def count_voxels(self, ray_idxs, cameras):
+        """int32 [n_images, n] voxel counts (what rn_scene_count_voxels returns)."""
+        cam = cameras.numpy()
+        N = self.N
+        out = np.zeros((len(cam), len(ray_idxs)), np.int32)
+        for k in range(len(cam)):
+            s, e = self.o.sample(ray_idxs.numpy(), cam[k, 12 * N:12 * N + 12], cam[k, 12 * N + 12:])
+            out[k] = self.o.traversal(s, e)[1]
+        return torch.from_numpy(out)
 
     def scene_prepare(self, ridx, feature_views, P, P_inv, center, vox, rvc, Sr, order=None):
         feats = np.stack([f.numpy() for f in feature_views])

@@ -261,38 +261,134 @@ def _rank_main(rank, world, port, out_dir, deterministic=False):
                                             (H, W), 0, deterministic=deterministic)
     depths = list(fp.forward_pass(scene, (0, 5, 1)))
     np.savez(os.path.join(out_dir, "%sw%d_r%d.npz" % ("d" if deterministic else "", world, rank)),
-             depth=np.stack(depths), acc=fp.accumulator.cpu().numpy())
+             depth=np.stack(depths), acc=fp.accumulator.cpu().numpy(),
+             rows=np.array([len(fp.ray_index[r]) for r in range(5)]),
+             balance=np.array(fp.shard_balance if fp.shard_balance is not None else []))
     if world > 1:
         dist.destroy_process_group()
 
 
-def test_sharded_ranks_on_real_kernels(torch, tmp_path):
-    """Two ranks (gloo, both on cuda:0 -- RCCL needs one GPU per rank) run the real HIP
-    kernels on their ray shards; the merged accumulator and depth maps equal the
-    single-rank run (prior counted once)."""
+def _free_port():
     import socket
-    import torch.multiprocessing as mp
-    out = str(tmp_path)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_ranks_on_real_kernels(torch, tmp_path, world):
+    """2 / 4 / 8 ranks (gloo, all on cuda:0 -- RCCL needs one GPU per rank) run the real HIP
+    kernels on their voxel-balanced ray shards; the merged accumulator and depth maps equal
+    the single-rank run (prior counted once) and are the same on every rank."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_rank_main, args=(0, 1, 0, out))]
     procs[0].start()
     procs[0].join(300)
     assert procs[0].exitcode == 0
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(300)
+        p.join(600)
         assert p.exitcode == 0
     one = np.load(out + "/w1_r0.npz")
-    r0, r1 = np.load(out + "/w2_r0.npz"), np.load(out + "/w2_r1.npz")
-    assert np.array_equal(r0["acc"], r1["acc"]) and np.array_equal(r0["depth"], r1["depth"])
+    ranks = [np.load(out + "/w%d_r%d.npz" % (world, q)) for q in range(world)]
+    r0 = ranks[0]
+    for rq in ranks[1:]:
+        assert np.array_equal(r0["acc"], rq["acc"]) and np.array_equal(r0["depth"], rq["depth"])
+        assert np.array_equal(r0["balance"], rq["balance"])
     assert np.abs(one["acc"] - r0["acc"]).max() < 5e-3
     assert (np.abs(one["depth"] - r0["depth"]) > 1e-4).mean() < 0.01
+    # every ray owned once; voxel visits per rank within 10 % of the mean (cuts on 64-row
+    # boundaries of 3072-row images here; 5 % at config-2 size, tools/shard_proxy.py)
+    rows = np.stack([rq["rows"] for rq in ranks])
+    assert np.all(rows.sum(0) == 48 * 64)
+    bal = r0["balance"].sum(0).astype(np.float64)
+    assert len(bal) == world and np.all(np.abs(bal / bal.mean() - 1) < 0.10), bal
+
+
+def _nccl_single_main(port, out_dir):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    H, W = 48, 64
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    res = {}
+    for det in (False, True):
+        fp = get_forward_pass_factory("raynet")(bank, _gp(32, 192, (64, 64, 64)), "sample_in_bbox",
+                                                (H, W), 0, deterministic=det)
+        depths = list(fp.forward_pass(scene, (0, 5, 1)))
+        res["d" if det else "f"] = (np.stack(depths), fp.accumulator.cpu().numpy())
+    np.savez(os.path.join(out_dir, "nccl.npz"), depth=res["f"][0], acc=res["f"][1],
+             depth_fixed=res["d"][0], acc_fixed=res["d"][1])
+    dist.destroy_process_group()
+
+
+def test_rccl_code_path_in_a_one_rank_world(torch, tmp_path):
+    """The collectives of the sharded path -- float all-reduce of the partial accumulator,
+    int64 all-reduce in the deterministic mode, all_gather_into_tensor of the depth rows --
+    executed by RCCL itself (backend "nccl") in a process group of ONE rank: what a
+    single-GPU box can run of BASELINE.json config 3's exchange.  Results equal the run
+    without a process group."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_single_main, args=(_free_port(), out))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    for det in (False, True):
+        q = ctx.Process(target=_rank_main, args=(0, 1, 0, out, det))
+        q.start()
+        q.join(300)
+        assert q.exitcode == 0
+    got = np.load(out + "/nccl.npz")
+    ref, ref_d = np.load(out + "/w1_r0.npz"), np.load(out + "/dw1_r0.npz")
+    assert np.abs(got["acc"] - ref["acc"]).max() < 5e-3
+    assert (np.abs(got["depth"] - ref["depth"]) > 1e-4).mean() < 0.01
+    assert np.array_equal(got["acc_fixed"], ref_d["acc"])          # fixed point: the same bits
+    assert np.array_equal(got["depth_fixed"], ref_d["depth"])
+
+
+def test_resident_schedule_in_memory_bounded_groups(torch, monkeypatch):
+    """When the per-ray columns of all reference images do not fit the HBM budget, the
+    resident schedule keeps the messages and recomputes lists + columns group by group in
+    every sweep (what the reference does for everything): same results as all-resident."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W = 48, 64
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(32, 192, (64, 64, 64))
+    runs = []
+    for budget in (None, "0.027", "0.0235"):
+        if budget is None:
+            monkeypatch.delenv("RAYNET_RESIDENT_GB", raising=False)
+        else:
+            monkeypatch.setenv("RAYNET_RESIDENT_GB", budget)
+        fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0,
+                                                deterministic=True)
+        depths = np.stack(list(fp.forward_pass(scene, (0, 5, 1))))
+        runs.append((depths, fp.accumulator.cpu().numpy(), [len(g) for g in fp._plan["groups"]]))
+    assert runs[0][2] == [5] and runs[1][2] == [2, 2, 1] and runs[2][2] == [1] * 5
+    for d, acc, _ in runs[1:]:                      # fixed-point sums: the same bits
+        assert np.array_equal(acc, runs[0][1]) and np.array_equal(d, runs[0][0])
+    monkeypatch.setenv("RAYNET_RESIDENT_GB", "0.001")
+    fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0)
+    with pytest.raises(MemoryError):
+        list(fp.forward_pass(scene, (0, 5, 1)))
 
 
 @pytest.mark.parametrize("filter_rays", [False, True])

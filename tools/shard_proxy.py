@@ -25,7 +25,7 @@ gp = GenerationParameters(depth_planes=64, neighbors=4, grid_shape=np.array([128
 
 
 class FakeDist(object):
-    ReduceOp = types.SimpleNamespace(SUM=0)
+    ReduceOp = types.SimpleNamespace(SUM=0, MIN=1, MAX=2)
 
     def __init__(self, world):
         self.world = world
@@ -39,7 +39,7 @@ class FakeDist(object):
 
 res = {}
 for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
-    for rank in sorted({0, world // 2}):
+    for rank in (range(world) if os.environ.get("ALL_RANKS") else sorted({0, world // 2})):
         fake = FakeDist(world)
         F._dist = (lambda f=fake, r=rank, w=world: (f, r, w)) if world > 1 else (lambda: (None, 0, 1))
         fp = F.get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0)
@@ -70,6 +70,11 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
         res[(world, rank)] = ms
         print("world %d rank %d: %.3f ms/step  kernels %.3f  (%s)" % (
             world, rank, ms, sum(fam.values()), " ".join("%s=%.3f" % kv for kv in sorted(fam.items()))))
+        if fp.shard_balance is not None and rank == 0:
+            bal = np.array(fp.shard_balance, dtype=np.float64).sum(0)
+            rows = [fp._plan["bounds"][0][q + 1] - fp._plan["bounds"][0][q] for q in range(world)]
+            print("   voxel visits per rank / mean: %s   rows per image: %s" % (
+                np.round(bal / bal.mean(), 3).tolist(), rows))
 t1 = res.get((1, 0))
 for world in ([2, 4, 8] if t1 else []):
     if (world, 0) not in res:
