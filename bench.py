@@ -250,27 +250,39 @@ def main():
                 o.fused_depth(ridx[k], f, P, Pi, cc, vg, acc, msgs[k])
             return time.perf_counter() - t, kept
 
-        probe = min(400, H * W)
-        tp, _ = cpu_run(probe)
-        n = int(min(H * W, max(probe, probe * 0.6 * args.cpu_seconds / max(tp, 1e-6))))
-        tc, _ = cpu_run(n)
+        # grow the sample until a run takes about the time budget (small samples are all
+        # OpenMP start-up; the rate is only meaningful once every core has rays)
+        target = 0.6 * args.cpu_seconds
+        n = min(2000, H * W)
+        while True:
+            tc, _ = cpu_run(n)
+            if tc >= 0.5 * target or n >= H * W:
+                break
+            n = int(min(H * W, n * min(8.0, max(2.0, target / max(tc, 1e-6)))))
         port = dict(value=round(V * n / tc, 1), unit="rays/s", cores=threads, kind="port",
                     sample="%d rays of each of the %d reference images (of %d per step), 3 BP "
                            "sweeps + depth sweep with the oracle's fused K1/K2 "
                            "(oracle/raynet_oracle.c, OpenMP), %.1f s" % (n, V, rays_per_step, tc))
-        # NumPy leg: ~70-110 us per ray and sweep, single process
-        n_np = max(50, int(0.4 * args.cpu_seconds / (4 * 100e-6) / V))
-        _, kept = cpu_run(n_np, keep=True)
-        rvi = np.concatenate([k[0] for k in kept])
-        rvc = np.concatenate([k[1] for k in kept])
-        Sv = np.concatenate([k[2] for k in kept])
-        t = time.perf_counter()
-        m_np = np.zeros_like(Sv)
-        acc_np, m_np = cpu_reference.belief_propagation(Sv, rvi, rvc, m_np, cfg["grid"],
-                                                        gamma=0.05, bp_iterations=3)
-        cpu_reference.compute_depth_distribution(Sv, rvi, rvc, m_np, acc_np)
-        tn = time.perf_counter() - t
-        numpy_leg = dict(value=round(len(rvc) / tn, 1), unit="rays/s", cores=1,
+
+        def numpy_run(n_np):
+            _, kept = cpu_run(n_np, keep=True)
+            rvi = np.concatenate([k[0] for k in kept])
+            rvc = np.concatenate([k[1] for k in kept])
+            Sv = np.concatenate([k[2] for k in kept])
+            t = time.perf_counter()
+            m_np = np.zeros_like(Sv)
+            acc_np, m_np = cpu_reference.belief_propagation(Sv, rvi, rvc, m_np, cfg["grid"],
+                                                            gamma=0.05, bp_iterations=3)
+            cpu_reference.compute_depth_distribution(Sv, rvi, rvc, m_np, acc_np)
+            return time.perf_counter() - t, len(rvc)
+
+        n_np = min(1000, H * W)
+        tn, rays_np = numpy_run(n_np)
+        want = 0.4 * args.cpu_seconds
+        if tn < 0.5 * want and n_np < H * W:
+            n_np = int(min(H * W, n_np * want / max(tn, 1e-6)))
+            tn, rays_np = numpy_run(n_np)
+        numpy_leg = dict(value=round(rays_np / tn, 1), unit="rays/s", cores=1,
                          kind="numpy_restatement",
                          sample="%d rays of each of the %d reference images; the reference's "
                                 "NumPy path (mrf/mrf_np.py semantics, oracle/cpu_reference.py: "

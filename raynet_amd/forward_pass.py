@@ -557,8 +557,11 @@ class RayNetForwardPass(ForwardPass):
             torch.cuda.current_stream(dev).wait_stream(self._side_stream)
         acc_in.fill_(prior)
         acc_part.zero_()
-        if self.bp_iterations == 0:
-            msgs_all.zero_()          # the depth sweep then reads the initial (zero) messages
+        if self.bp_iterations == 0 or self.reference_quirks:
+            # no sweep writes them (the depth sweep then reads the initial, zero messages) /
+            # quirk Q2 decodes every image with the LAST image's rows, beyond that image's own
+            # counts: the reference's zero-filled memmap is zero there
+            msgs_all.zero_()
 
         per_image = {}
         for k, r in enumerate(refs):

@@ -34,16 +34,21 @@ class PerPixelMeanDepthError(Metric):
         self.borders = borders
 
     def compute(self, scene, frame_idxs, depthmaps, predicted_pointcloud):
-        metric = np.zeros((len(frame_idxs),))
+        """-> (mean |ground truth - prediction| per frame over the pixels that HAVE ground
+        truth, None); a frame's border of `borders` pixels is left out."""
         H, W = scene.image_shape
-        bordersH = slice(self.borders, H - self.borders)
-        bordersW = slice(self.borders, W - self.borders)
-        for i, (fi, d) in enumerate(zip(frame_idxs, depthmaps)):
-            G = scene.get_depth_map(fi)[bordersH, bordersW]
-            D = (np.load(d) if isinstance(d, str) else np.asarray(d))[bordersH, bordersW]
-            pixels = G != 0
-            metric[i] = np.abs(G[pixels] - D[pixels]).mean()
-        return metric, None
+        b = self.borders
+        inner = (slice(b, H - b), slice(b, W - b))
+
+        def frame_error(frame, prediction):
+            truth = scene.get_depth_map(frame)[inner]
+            if isinstance(prediction, str):
+                prediction = np.load(prediction)
+            known = truth != 0
+            return np.abs(truth[known] - np.asarray(prediction)[inner][known]).mean()
+
+        errors = [frame_error(f, d) for f, d in zip(frame_idxs, depthmaps)]
+        return np.array(errors, dtype=np.float64).reshape(len(frame_idxs)), None
 
 
 class _CloudMetric(Metric):

@@ -5,6 +5,13 @@ filters, BatchNorm], ReLU after the first four.  Five valid 3x3 convolutions shr
 (H+2p) x (W+2p) zero-padded image with p = 11 to (H+p+1) x (W+p+1), the feature-map
 extent the kernels index (feature_similarities.cu:73-74).  The reference ships no
 weights, so this is random-initialised; `predict` mirrors Keras' NHWC in / NHWC out.
+
+Trained reference weights come in through `load_reference_weights`: the reference reads
+them from its HDF5 file in the order `[w for l in model.layers for w in l.weights]`
+(raynet/models.py:329-339), which for this network is, per block, Conv2D `kernel`
+[3, 3, c_in, c_out] and `bias` [c_out], then BatchNormalization `gamma`, `beta`,
+`moving_mean`, `moving_variance` [c_out] -- 30 arrays.  HDF5 cannot be read in this image
+(no h5py); the same list saved with `numpy.savez(path, *weights)` can.
 """
 import numpy as np
 import torch
@@ -27,6 +34,53 @@ class SimpleCNN(nn.Module):
 
     def forward(self, x):           # NCHW
         return self.net(x)
+
+    # ---- weights in the reference's (Keras) order and layouts -----------------------
+    def _blocks(self):
+        mods = list(self.net)
+        return [(mods[i], mods[i + 1]) for i in range(len(mods)) if isinstance(mods[i], nn.Conv2d)]
+
+    @torch.no_grad()
+    def load_reference_weights(self, weights):
+        """weights: the 30 arrays of `model.get_weights()` / models.py:333-337, as a list, or
+        the path of (or an open) `.npz` written with `numpy.savez(path, *weights)`."""
+        if isinstance(weights, (str, bytes)) or hasattr(weights, "read"):
+            weights = np.load(weights)
+        if hasattr(weights, "files"):        # NpzFile: arr_0, arr_1, ... in positional order
+            weights = [weights["arr_%d" % i] for i in range(len(weights.files))]
+        weights = [np.asarray(w, dtype=np.float32) for w in weights]
+        blocks = self._blocks()
+        if len(weights) != 6 * len(blocks):
+            raise ValueError("expected %d arrays (kernel, bias, gamma, beta, moving_mean, "
+                             "moving_variance per block), got %d" % (6 * len(blocks), len(weights)))
+        for b, (conv, bn) in enumerate(blocks):
+            kernel, bias, gamma, beta, mean, var = weights[6 * b:6 * b + 6]
+            want = (3, 3, conv.in_channels, conv.out_channels)
+            if tuple(kernel.shape) != want:
+                raise ValueError("block %d: kernel %s, expected %s" % (b, kernel.shape, want))
+            for name, a in (("bias", bias), ("gamma", gamma), ("beta", beta),
+                            ("moving_mean", mean), ("moving_variance", var)):
+                if tuple(a.shape) != (conv.out_channels,):
+                    raise ValueError("block %d: %s has shape %s" % (b, name, a.shape))
+            dev = conv.weight.device
+            # Keras HWIO -> torch OIHW; both frameworks correlate (no kernel flip)
+            conv.weight.copy_(torch.from_numpy(kernel).permute(3, 2, 0, 1).contiguous().to(dev))
+            conv.bias.copy_(torch.from_numpy(bias).to(dev))
+            bn.weight.copy_(torch.from_numpy(gamma).to(dev))
+            bn.bias.copy_(torch.from_numpy(beta).to(dev))
+            bn.running_mean.copy_(torch.from_numpy(mean).to(dev))
+            bn.running_var.copy_(torch.from_numpy(var).to(dev))
+        return self
+
+    @torch.no_grad()
+    def reference_weights(self):
+        """The inverse: this network's weights as the reference's list of 30 arrays."""
+        out = []
+        for conv, bn in self._blocks():
+            out += [conv.weight.permute(2, 3, 1, 0).contiguous().cpu().numpy(),
+                    conv.bias.cpu().numpy(), bn.weight.cpu().numpy(), bn.bias.cpu().numpy(),
+                    bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy()]
+        return out
 
     @torch.no_grad()
     def predict(self, images_nhwc):

@@ -6,8 +6,9 @@ with the flags that reach the path -- same names, same defaults -- on MI355X.
         --forward_pass_factory raynet --depth_planes 32 --grid_shape 64,64,32 ...
 
 Loads a scene (Restrepo or DTU layout), builds the MV-CNN twin (random weights unless
---weight_file names a torch state_dict -- the reference's Keras files cannot be read here),
-runs `forward_pass(scene, (start, end, skip_every + 1))` and writes one `depth_%03d.npy`
+--weight_file is given: a `.npz` holding the reference's weight list in the reference's own
+order, raynet/models.py:329-339 -- `numpy.savez(path, *model.get_weights())` on the Keras
+side; HDF5 itself cannot be read in this image -- or a torch state_dict of the twin), runs `forward_pass(scene, (start, end, skip_every + 1))` and writes one `depth_%03d.npy`
 ((H, W) float32) per reference image, the wire format of scripts/forward_pass.py:136-142.
 """
 import argparse
@@ -26,7 +27,11 @@ def build_parser():
                                              "for the images of a scene"))
     p.add_argument("dataset_directory", help="Directory containing the input data")
     p.add_argument("output_directory", help="Directory to save the output data")
-    p.add_argument("--weight_file", help="torch state_dict of the MV-CNN twin (raynet_amd.models)")
+    p.add_argument("--weight_file", help="MV-CNN weights: .npz in the reference's weight order "
+                                         "(models.py:329-339) or a torch state_dict of the twin")
+    p.add_argument("--schedule", choices=["resident", "reference"], default="resident",
+                   help="raynet factory: per-ray columns resident in HBM (grouped by the free "
+                        "memory) / the reference's literal recompute-everything schedule")
     p.add_argument("--scene_idx", default=1, type=int, help="DTU: the scan number")
     p.add_argument("--filter_out", action="store_true", help="Filter out rays with zero ground-truth")
     # scripts/arguments.py:146-223 (generation)
@@ -55,13 +60,25 @@ def build_parser():
     return p
 
 
+def load_model(weight_file=None, architecture="simple_cnn", in_channels=3, device="cuda"):
+    """The MV-CNN twin with the weights of `weight_file` (see --weight_file)."""
+    import torch
+    from raynet_amd.models import get_nn
+    model = get_nn(architecture)(in_channels=in_channels).to(device)
+    if weight_file:
+        if str(weight_file).endswith(".npz"):
+            model.load_reference_weights(weight_file)
+        else:
+            model.load_state_dict(torch.load(weight_file, map_location=device))
+    return model
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     import torch
     from raynet_amd.common.generation_parameters import GenerationParameters
     from raynet_amd.common.scene import get_scene
     from raynet_amd.forward_pass import get_forward_pass_factory
-    from raynet_amd.models import get_nn
 
     if not os.path.exists(args.output_directory):
         os.makedirs(args.output_directory)
@@ -82,14 +99,14 @@ def main(argv=None):
         scene = get_scene("restrepo", args.dataset_directory,
                           select_neighbors_based_on=args.select_neighbors_based_on)
 
-    model = get_nn(args.network_architecture)(in_channels=scene.get_image(0).image.shape[2]).cuda()
-    if args.weight_file:
-        model.load_state_dict(torch.load(args.weight_file, map_location="cuda"))
+    model = load_model(args.weight_file, args.network_architecture,
+                       in_channels=scene.get_image(0).image.shape[2])
 
     cls = get_forward_pass_factory(args.forward_pass_factory)
     kwargs = dict(filter_out_rays=args.filter_out)
     if args.forward_pass_factory == "raynet":
         kwargs["bp_iterations"] = args.bp_iterations
+        kwargs["schedule"] = args.schedule
     fp = cls(model, generation_params, "sample_in_bbox", scene.image_shape, args.rays_batch, **kwargs)
 
     start, end = args.start_end
