@@ -62,9 +62,17 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
         const int i = ch * WAVE + lane;
         R.sv[ch] = 0.0f; R.mv[ch] = 0.0f; R.pk[ch] = 0;
         if (ch * WAVE < count && i < count) {
+            // -DRN_EXP_NO_SR / -DRN_EXP_NO_MSG: timing experiments only (wrong results): how
+            // much of the kernel's time is one 4-byte-per-voxel row read
+#ifdef RN_EXP_NO_SR
+            R.sv[ch] = 1.0f / count;
+#else
             R.sv[ch] = Srow[i];
+#endif
             R.pk[ch] = load_packed<PACKED>(vrow, i);
+#ifndef RN_EXP_NO_MSG
             if (mrow) R.mv[ch] = mrow[i];
+#endif
         }
     }
 }
@@ -560,7 +568,11 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             okmask |= (unsigned)ok << k;
             // rows of padding / short rays are read at the tile's first row: valid memory
             const int rr = ok ? r0 + j0 + k * STRIDE : r0, ss = ok ? st : 0;
+#ifdef RN_EXP_NO_SCATTER_MSG      // timing experiment only (wrong results)
+            m[k] = 1.0f;
+#else
             m[k] = msgs[(size_t)rr * p.M + ss];
+#endif
             v[k] = load_packed<PACKED>(vox + (size_t)rr * p.M * (PACKED ? 1 : 3), ss);
         }
         int lo0 = 1 << 30, lo1 = 1 << 30, lo2 = 1 << 30, hi0 = -1, hi1 = -1, hi2 = -1;

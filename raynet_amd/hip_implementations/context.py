@@ -21,11 +21,11 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _chk(t, dtype, min_numel=0, name="tensor", optional=False):
+def _chk(t, dtype, min_numel=0, name="tensor", optional=False, align=16):
     """The C ABI takes raw device pointers: a tensor handed to it must be what the kernels
     assume -- on the GPU, contiguous, of the stated dtype, at least `min_numel` elements, rows
-    16-byte aligned (the kernels use 128-bit loads) -- or the call fails HERE, not as a silent
-    out-of-bounds access."""
+    `align`-byte aligned (16: the kernels read rows with 128-bit loads) -- or the call fails
+    HERE, not as a silent out-of-bounds access."""
     if t is None:
         if optional:
             return t
@@ -38,8 +38,8 @@ def _chk(t, dtype, min_numel=0, name="tensor", optional=False):
         raise ValueError("%s: must be contiguous" % name)
     if t.numel() < min_numel:
         raise ValueError("%s: %d elements, need >= %d" % (name, t.numel(), min_numel))
-    if t.numel() and t.data_ptr() % 16:
-        raise ValueError("%s: data pointer is not 16-byte aligned" % name)
+    if t.numel() and t.data_ptr() % align:
+        raise ValueError("%s: data pointer is not %d-byte aligned" % (name, align))
     return t
 
 
@@ -302,7 +302,8 @@ class HipContext(object):
         for k, fv in enumerate(feature_views):
             _chk(fv, f32, fdim, "feature map %d" % k)
         _chk(ray_idxs, i32, n, "ray_idxs"); _chk(order, i32, n, "order", optional=True)
-        _chk(P, f32, 12 * self.N, "P"); _chk(P_inv, f32, 12, "P_inv"); _chk(center, f32, 3, "center")
+        _chk(P, f32, 12 * self.N, "P", align=4); _chk(P_inv, f32, 12, "P_inv", align=4)
+        _chk(center, f32, 3, "center", align=4)
         _chk(vox, i32, n * self.M, "vox"); _chk(rvc, i32, n, "rvc"); _chk(Sr, f32, n * self.M, "Sr")
         assert order is None or len(order) == n
         arr = (ctypes.c_void_p * self.N)(*[fv.data_ptr() for fv in feature_views])
@@ -317,9 +318,9 @@ class HipContext(object):
         cameras: float32 CUDA tensor [n_images, 12N + 16]."""
         n, rows = len(ray_idxs), int(n_images) * int(rows_per_image)
         f32, i32 = torch.float32, torch.int32
-        _chk(feature_table, torch.int64, n_images * self.N, "feature_table")
+        _chk(feature_table, torch.int64, n_images * self.N, "feature_table", align=8)
         assert tuple(feature_table.shape) == (n_images, self.N)
-        _chk(cameras, f32, n_images * (12 * self.N + 16), "cameras")
+        _chk(cameras, f32, n_images * (12 * self.N + 16), "cameras", align=4)
         assert tuple(cameras.shape) == (n_images, 12 * self.N + 16)
         _chk(ray_idxs, i32, n, "ray_idxs"); _chk(order, i32, n, "order", optional=True)
         _chk(vox, i32, rows * self.M, "vox"); _chk(rvc, i32, rows, "rvc")
@@ -334,7 +335,7 @@ class HipContext(object):
         """-> int32 [n_images, n]: voxels crossed by every ray of ray_idxs in every reference
         image (rn_scene_count_voxels; cameras as for scene_prepare_all)."""
         n_images, n = int(cameras.shape[0]), len(ray_idxs)
-        _chk(cameras, torch.float32, n_images * (12 * self.N + 16), "cameras")
+        _chk(cameras, torch.float32, n_images * (12 * self.N + 16), "cameras", align=4)
         _chk(ray_idxs, torch.int32, n, "ray_idxs")
         out = torch.zeros((n_images, n), dtype=torch.int32, device=self.device)
         self._check(self.lib.rn_scene_count_voxels(self._h, n_images, n, _ptr(ray_idxs),
@@ -393,7 +394,7 @@ class HipContext(object):
         _chk(depth_map, torch.float32, n, "depth_map", optional=True)
         groups = (n + rays_per_center - 1) // rays_per_center if rays_per_center > 0 else 1
         _chk(center, torch.float32, 4 * groups if rays_per_center > 0 else 3, "center",
-             optional=depth_map is None)
+             optional=depth_map is None, align=4)
         self._check(self.lib.rn_scene_depth(self._h, n, _ptr(Sr), _ptr(vox), _ptr(rvc),
                                             _ptr(acc), _ptr(msgs), _ptr(center),
                                             int(rays_per_center), _ptr(S_new), _ptr(depth_map),

@@ -72,7 +72,7 @@ def test_depth_to_voxels_and_selector(setup, oracle_mod):
     assert out is S_new
     want = o.planes_to_voxels(np.ascontiguousarray(vg.transpose(1, 2, 3, 0)), rvi[sel], rvc[sel],
                               s[sel], e[sel], S[sel])
-    assert np.abs(S_new[sel] - want).max() <= 2e-7
+    assert np.abs(S_new[sel] - want).max() <= 5e-7       # values <= 1: a few fp32 ulp
     rest = np.setdiff1d(all_rays, sel)
     assert np.all(S_new[rest] == 0)
     hit = rvc[sel] > 0
