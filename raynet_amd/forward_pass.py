@@ -302,10 +302,22 @@ class RayNetForwardPass(ForwardPass):
         self._de = None
         self.timings = {}
         # state kept for inspection by tests / tools
-        self.accumulator = None
+        self._acc_flat = self._acc_grid = None
         self.messages = _Messages()   # per image: [rows, M] messages of this rank's rays
         self.voxel_count = {}
         self.ray_index = {}      # per image: ray index (pixel x*H + y) of every row
+
+    @property
+    def accumulator(self):
+        """[gx][gy][gz] log-odds accumulator of the last pass (mrf_bp.cu:3-10 layout).  The
+        resident pass keeps it bricked; the regrid happens when somebody asks."""
+        if self._acc_grid is None and self._acc_flat is not None:
+            self._acc_grid = self._ctx.acc_to_grid(self._acc_flat)
+        return self._acc_grid
+
+    @accumulator.setter
+    def accumulator(self, value):
+        self._acc_grid, self._acc_flat = value, None
 
     # -- helpers -----------------------------------------------------------
     def _context(self, scene, F):
@@ -371,22 +383,25 @@ class RayNetForwardPass(ForwardPass):
         N = gp.neighbors + 1
         V = len(refs)
         stride = 12 * N + 12 + 4
+        views_of = {r: scene.view_indices_with_neighbors(r, gp.neighbors) for r in refs}
+        ptrs = tuple(tuple(bank[v].data_ptr() for v in views_of[r]) for r in refs)
+        patch_rows = self.ray_tile is not None
+        # the plan of a scene OBJECT is reused as long as the object lives (its cameras are
+        # immutable: K, R, t are constructor arguments, common/camera.py), the feature maps
+        # sit where they sat and nothing that shapes the plan changed
+        key = (id(scene), ptrs, tuple(refs), H, W, M, N, world, rank, self.ray_tile,
+               self.sweep_reorder, self.rays_batch, self.deterministic, str(dev),
+               os.environ.get("RAYNET_TILE_ALONG", "auto"), os.environ.get("RAYNET_SHARD", "voxels"),
+               os.environ.get("RAYNET_RESIDENT_GB", "0"))
+        plan = self._plan
+        if plan is not None and plan["key"] == key and not self._filter_out_rays:
+            return plan
         cam_host = np.zeros((V, stride), dtype=np.float32)
-        views_of = {}
         for k, r in enumerate(refs):
-            views_of[r] = scene.view_indices_with_neighbors(r, gp.neighbors)
             P, P_inv, center = self._camera_arrays([scene.get_image(v) for v in views_of[r]])
             cam_host[k, :12 * N] = P.ravel()
             cam_host[k, 12 * N:12 * N + 12] = P_inv.ravel()
             cam_host[k, 12 * N + 12:] = center
-        ptrs = tuple(tuple(bank[v].data_ptr() for v in views_of[r]) for r in refs)
-        patch_rows = self.ray_tile is not None
-        key = (cam_host.tobytes(), ptrs, tuple(refs), H, W, M, world, rank, self.ray_tile,
-               self.sweep_reorder, self.rays_batch, self.deterministic, str(dev),
-               os.environ.get("RAYNET_TILE_ALONG", "auto"), os.environ.get("RAYNET_SHARD", "voxels"))
-        plan = self._plan
-        if plan is not None and plan["key"] == key and not self._filter_out_rays:
-            return plan
         # all camera matrices go up in ONE copy: a pageable host->device copy is a stream
         # synchronisation point, one per image would drain the GPU between images
         cam_dev = ctx.dev(cam_host)
@@ -497,7 +512,7 @@ class RayNetForwardPass(ForwardPass):
             if plan is not None:                     # the outgoing plan's buffers are reusable
                 free += plan["bytes"]
             budget = 0.9 * free
-        fixed = V * per_image + 3 * G * 8 + V * npad * 48
+        fixed = V * per_image + 4 * G * 8 + V * npad * 48
         if budget > 0 and fixed + 2 * per_image > budget:
             raise MemoryError(
                 "resident schedule: the messages of %d reference images (%.1f GB) do not leave "
@@ -508,8 +523,10 @@ class RayNetForwardPass(ForwardPass):
         self._plan = plan = None                     # release the old buffers first
         rows_g = Vg * npad
         fixed_pt = self.deterministic and hasattr(ctx, "scene_bp_sweep_fixed")
+        prior = self._prior()
         plan = dict(
-            key=key, cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
+            key=key, scene=scene, prior=prior, dirty=False,
+            cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
             balance=balance, shards=shards, npad=npad, groups=groups, Vg=Vg, shared=shared,
             patch_rows=patch_rows, fixed=fixed_pt,
             table=torch.tensor(ptrs, dtype=torch.int64).to(dev) if V else None,
@@ -518,11 +535,23 @@ class RayNetForwardPass(ForwardPass):
             msgs=torch.empty((V * npad, M), dtype=torch.float32, device=dev),   # see _Messages
             rvc=torch.zeros((V * npad,), dtype=torch.int32, device=dev),   # padding rays: count 0
             depth=torch.zeros((V * npad,), dtype=torch.float32, device=dev),
+            # iteration 0 reads the prior from a buffer no sweep ever writes (no refill per pass)
+            acc_prior=torch.full((G,), prior, dtype=torch.float32, device=dev),
             acc_a=torch.empty((G,), dtype=torch.float32, device=dev),
             acc_b=torch.empty((G,), dtype=torch.float32, device=dev),
             acc_part=(torch.zeros((G,), dtype=torch.int64, device=dev) if fixed_pt else
                       torch.zeros((ctx.acc_copies(), G), dtype=torch.float32, device=dev)),
             bytes=fixed + 2 * rows_g * M * 4, orders={}, stitch=None)
+        # static views of every image's rows in the scene-wide buffers
+        per_image = {}
+        for k, r in enumerate(refs):
+            ridx, lo, hi, total = shards[k]
+            n, row0 = len(ridx), k * npad
+            per_image[r] = dict(k=k, ridx=ridx, n=n, lo=lo, hi=hi, total=total, row0=row0,
+                                center=cam_dev[k, 12 * N + 12:],
+                                rvc=plan["rvc"][row0:row0 + n], msgs=plan["msgs"][row0:row0 + n],
+                                depth=plan["depth"][row0:row0 + n])
+        plan["per_image"] = per_image
         if not self._filter_out_rays:
             self._plan = plan
         return plan
@@ -545,6 +574,7 @@ class RayNetForwardPass(ForwardPass):
         prior = self._prior()
         N = gp.neighbors + 1
         V = len(refs)
+        self._acc_flat = self._acc_grid = None
         plan = self._build_plan(scene, refs, bank, ctx, dist, rank, world)
         cam_dev, views_of, lists, shards = plan["cam_dev"], plan["views_of"], plan["lists"], plan["shards"]
         npad, groups, patch_rows, fixed = plan["npad"], plan["groups"], plan["patch_rows"], plan["fixed"]
@@ -552,26 +582,23 @@ class RayNetForwardPass(ForwardPass):
         self.shard_balance = plan["balance"]
         # resident accumulators are flat buffers in the backend's own layout (4x4x4 bricks
         # on the GPU, include/raynet_hip.h); `self.accumulator` is handed out as [gx][gy][gz]
-        acc_in, acc_next, acc_part = plan["acc_a"], plan["acc_b"], plan["acc_part"]
+        acc_in, acc_next, acc_spare, acc_part = plan["acc_prior"], plan["acc_a"], plan["acc_b"], plan["acc_part"]
         if self._side_stream is not None:      # an abandoned earlier pass may still be copying
             torch.cuda.current_stream(dev).wait_stream(self._side_stream)
-        acc_in.fill_(prior)
-        acc_part.zero_()
+        if plan["prior"] != prior:
+            plan["prior"] = prior
+            acc_in.fill_(prior)
+        if plan["dirty"]:                      # an earlier pass was abandoned inside an iteration
+            acc_part.zero_()
         if self.bp_iterations == 0 or self.reference_quirks:
             # no sweep writes them (the depth sweep then reads the initial, zero messages) /
             # quirk Q2 decodes every image with the LAST image's rows, beyond that image's own
             # counts: the reference's zero-filled memmap is zero there
             msgs_all.zero_()
 
-        per_image = {}
-        for k, r in enumerate(refs):
-            ridx, lo, hi, total = shards[k]
-            n = len(ridx)
-            row0 = k * npad
-            self.ray_index[r] = ridx
-            per_image[r] = dict(k=k, ridx=ridx, n=n, lo=lo, hi=hi, total=total, row0=row0,
-                                center=cam_dev[k, 12 * N + 12:],
-                                rvc=rvc_all[row0:row0 + n], msgs=msgs_all[row0:row0 + n])
+        per_image = plan["per_image"]
+        for r in refs:
+            self.ray_index[r] = per_image[r]["ridx"]
 
         def order_for(ridx_slice, lo_i, hi_i, images):
             # patch rows are already compact in both image directions (measured: the
@@ -631,6 +658,7 @@ class RayNetForwardPass(ForwardPass):
             # iteration 0 starts from zero messages (forward_pass.py:613-615); with the
             # shipped quirk every iteration does (memmap reopened with mode="w+", Q1)
             first = it == 0 or self.reference_quirks
+            plan["dirty"] = True
             for group in groups:
                 if not one_group:
                     prepare(group)
@@ -649,8 +677,10 @@ class RayNetForwardPass(ForwardPass):
             if collective:
                 dist.all_reduce(acc_part, op=dist.ReduceOp.SUM)
             combine(acc_part, prior, acc_next)
-            acc_in, acc_next = acc_next, acc_in
-        self.accumulator = ctx.acc_to_grid(acc_in)
+            # (the prior buffer never becomes a destination)
+            acc_in, acc_next = acc_next, (acc_spare if it == 0 else acc_in)
+            plan["dirty"] = False
+        self._acc_flat = acc_in            # `self.accumulator` regrids it when somebody looks
 
         # depth sweep.  One rank: image by image, and while image k+1 is decoded a side stream
         # maps image k's rows to pixels and copies the map to (pinned) host memory -- the
@@ -691,7 +721,7 @@ class RayNetForwardPass(ForwardPass):
                     msgs = st["msgs"]
                     if self.reference_quirks and last["n"] == st["n"]:
                         msgs = last["msgs"]   # every image decoded with the LAST one's
-                    dst = depth_all[st["row0"]:st["row0"] + st["n"]]
+                    dst = st["depth"]
                     Sr_k, vox_k = Sr_g[j * npad:j * npad + st["n"]], vox_g[j * npad:j * npad + st["n"]]
                     B = self.rays_batch // 256 * 256 if self.rays_batch and self.rays_batch >= 256 \
                         else max(st["n"], 1)
