@@ -112,6 +112,15 @@ struct rn_ctx {
     bool box_pin;         // RAYNET_HIP_BOX_PIN: stay at the starting level (A/B runs)
     unsigned *box_stats, *box_stats_host;
     hipEvent_t ev0, ev1;
+    // second stream of the resident-scene launchers (RAYNET_HIP_OVERLAP=1, default off): the
+    // accumulator scatter of one half of a launch's rows runs next to the BP sweep of the
+    // other half, the traversal of half of the images next to the plane sweep of the rest.
+    // Measured (profiles/r02_exp_overlap.txt): config 2 8.72 -> 8.84 ms/step (either kernel
+    // alone already keeps the VALUs of every CU busy), config 4 44.3 -> 42.5 (its scatter
+    // waits on L2 atomics: 3.9 hits per voxel)
+    bool overlap;
+    hipStream_t aux;
+    hipEvent_t ev_fork, ev_join;
     // per-launch profiling (rn_prof_begin / rn_prof_end)
     bool prof_on;
     int prof_cap, prof_n;
@@ -239,26 +248,56 @@ inline int box_split(int n, int tile_rays) {
 
 // One BP sweep: k_bp (messages) + the accumulator scatter that fits the row layout.
 template <bool PACKED, bool CLIP_IN>
+void launch_bp_kernel(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
+                      const float *acc_in, const float *msgs_in, float *msgs_out, hipStream_t st,
+                      bool uniform_acc) {
+    const int nch = (ctx->p.M + WAVE - 1) / WAVE;
+    ProfScope prof(ctx, RN_K_BP, n, st);
+#define RN_BP(NCH_)                                                                            \
+    hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
+                       ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, msgs_out, uniform_acc ? 1 : 0)
+    if (nch <= 2) RN_BP(2);
+    else if (nch <= 4) RN_BP(4);
+    else if (nch <= 6) RN_BP(6);
+    else if (nch <= 8) RN_BP(8);
+    else if (nch <= 12) RN_BP(12);
+    else RN_BP(16);
+#undef RN_BP
+}
+
+// the scatter kernel for `level` (see launch_bp) over rows [0, n)
+template <bool PACKED>
+void launch_scatter_kernel(rn_ctx *ctx, int n, const float *msgs, const int32_t *vox,
+                           const int32_t *rvc, void *acc_out, hipStream_t st, int level,
+                           bool fixed) {
+    ProfScope prof(ctx, RN_K_SCATTER, n, st);
+#define RN_BOX(RAYS, STEPS, FIXED_, CAP)                                                          \
+    hipLaunchKernelGGL((k_scatter_box<PACKED, RAYS, STEPS, FIXED_>),                              \
+                       dim3((n + RAYS - 1) / RAYS, box_split(n, RAYS)), dim3(BLOCK),              \
+                       (CAP) * sizeof(double), st, ctx->p, n, msgs, vox, rvc, acc_out,            \
+                       ctx->box_stats, CAP)
+    if (level == 0) {
+        if (fixed) RN_BOX(128, 32, true, 4096); else RN_BOX(128, 32, false, 4096);
+    } else if (level == 1) {
+        if (fixed) RN_BOX(256, 16, true, 6144); else RN_BOX(256, 16, false, 6144);
+    } else if (fixed) {
+        hipLaunchKernelGGL((k_scatter_direct_fixed<PACKED>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st,
+                           ctx->p, n, msgs, vox, rvc, static_cast<unsigned long long *>(acc_out));
+    } else {
+        hipLaunchKernelGGL((k_scatter_slab<PACKED>),
+                           dim3(((n + WAVE - 1) / WAVE) *
+                                ((ctx->p.M + SLAB_STEPS - 1) / SLAB_STEPS)),
+                           dim3(WAVE), 0, st, ctx->p, n, msgs, vox, rvc,
+                           static_cast<float *>(acc_out));
+    }
+#undef RN_BOX
+}
+
+template <bool PACKED, bool CLIP_IN>
 int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
               const float *acc_in, const float *msgs_in, void *acc_out, float *msgs_out,
               hipStream_t st, bool patch_rows = false, bool fixed = false,
               bool uniform_acc = false) {
-    const int nch = (ctx->p.M + WAVE - 1) / WAVE;
-    {
-        ProfScope prof(ctx, RN_K_BP, n, st);
-#define RN_BP(NCH_)                                                                            \
-    hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
-                       ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, msgs_out, uniform_acc ? 1 : 0)
-        if (nch <= 2) RN_BP(2);
-        else if (nch <= 4) RN_BP(4);
-        else if (nch <= 6) RN_BP(6);
-        else if (nch <= 8) RN_BP(8);
-        else if (nch <= 12) RN_BP(12);
-        else RN_BP(16);
-#undef RN_BP
-    }
-    RN_LAUNCH_CHECK(ctx);
-    ProfScope prof(ctx, RN_K_SCATTER, n, st);
     // Patch-ordered rows start with the LDS-box scatter on 128-ray x 32-step tiles.  The
     // kernel counts the chunks whose bounding box did not fit its LDS budget; the count of
     // the previous launches is copied out asynchronously (it may lag a launch) and when too
@@ -279,27 +318,31 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
         }
         level = ctx->box_level;
     }
-#define RN_BOX(RAYS, STEPS, FIXED_, CAP)                                                          \
-    hipLaunchKernelGGL((k_scatter_box<PACKED, RAYS, STEPS, FIXED_>),                              \
-                       dim3((n + RAYS - 1) / RAYS, box_split(n, RAYS)), dim3(BLOCK),              \
-                       (CAP) * sizeof(double), st, ctx->p, n, msgs_out, vox, rvc, acc_out,        \
-                       ctx->box_stats, CAP)
-    if (level == 0) {
-        if (fixed) RN_BOX(128, 32, true, 4096); else RN_BOX(128, 32, false, 4096);
-    } else if (level == 1) {
-        if (fixed) RN_BOX(256, 16, true, 6144); else RN_BOX(256, 16, false, 6144);
-    } else if (fixed) {
-        hipLaunchKernelGGL((k_scatter_direct_fixed<PACKED>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st,
-                           ctx->p, n, msgs_out, vox, rvc,
-                           static_cast<unsigned long long *>(acc_out));
+    // k_bp is bound by VALU issue and its dependent row / gather round trips, the box scatter
+    // by LDS atomics and barriers: with the rows in two halves the scatter of the first half
+    // runs (on the context's second stream) while the second half's messages are computed.
+    const size_t M = (size_t)ctx->p.M, VW = PACKED ? 1 : 3;
+    const int nA = ctx->overlap && PACKED && n >= 65536 ? (n / 2 + 255) / 256 * 256 : n;
+    launch_bp_kernel<PACKED, CLIP_IN>(ctx, nA, Sv, vox, rvc, acc_in, msgs_in, msgs_out, st, uniform_acc);
+    RN_LAUNCH_CHECK(ctx);
+    if (nA < n) {
+        RN_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+        launch_bp_kernel<PACKED, CLIP_IN>(ctx, n - nA, Sv + nA * M, vox + nA * M * VW, rvc + nA, acc_in,
+                                          msgs_in ? msgs_in + nA * M : nullptr, msgs_out + nA * M, st,
+                                          uniform_acc);
+        RN_LAUNCH_CHECK(ctx);
+        RN_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        launch_scatter_kernel<PACKED>(ctx, nA, msgs_out, vox, rvc, acc_out, ctx->aux, level, fixed);
+        RN_LAUNCH_CHECK(ctx);
+        RN_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+        launch_scatter_kernel<PACKED>(ctx, n - nA, msgs_out + nA * M, vox + nA * M * VW, rvc + nA,
+                                      acc_out, st, level, fixed);
+        RN_LAUNCH_CHECK(ctx);
+        RN_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     } else {
-        hipLaunchKernelGGL((k_scatter_slab<PACKED>),
-                           dim3(((n + WAVE - 1) / WAVE) *
-                                ((ctx->p.M + SLAB_STEPS - 1) / SLAB_STEPS)),
-                           dim3(WAVE), 0, st, ctx->p, n, msgs_out, vox, rvc,
-                           static_cast<float *>(acc_out));
+        launch_scatter_kernel<PACKED>(ctx, n, msgs_out, vox, rvc, acc_out, st, level, fixed);
+        RN_LAUNCH_CHECK(ctx);
     }
-#undef RN_BOX
     if (level < LAST) {
         (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
                              hipMemcpyDeviceToHost, st);
@@ -384,6 +427,8 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     const char *bs = getenv("RAYNET_HIP_BOX_LEVEL");      // A/B knob: start at this tile shape
     ctx->box_level = ctx->box_level0 = bs ? max(0, min(2, atoi(bs))) : 0;
     ctx->box_pin = getenv("RAYNET_HIP_BOX_PIN") != nullptr;
+    const char *ov = getenv("RAYNET_HIP_OVERLAP");
+    ctx->overlap = ov && atoi(ov) != 0;
     if (sweep_lds(p) > 160 * 1024) {      // before anything is allocated
         delete ctx;
         return RN_ERR_INVALID;
@@ -392,7 +437,10 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
         hipMalloc(&ctx->box_stats, 2 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc(&ctx->box_stats_host, 2 * sizeof(unsigned)) != hipSuccess ||
         hipMemset(ctx->box_stats, 0, 2 * sizeof(unsigned)) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         rn_destroy(ctx);                  // frees whatever was created (all null-checked)
         return RN_ERR_HIP;
     }
@@ -409,6 +457,9 @@ void rn_destroy(rn_ctx *ctx) {
     if (ctx->box_stats_host) hipHostFree(ctx->box_stats_host);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    if (ctx->aux) hipStreamDestroy(ctx->aux);
     for (int i = 0; i < 2 * ctx->prof_cap; i++) hipEventDestroy(ctx->prof_ev[i]);
     delete[] ctx->prof_ev;
     delete[] ctx->prof_id;
@@ -724,25 +775,55 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
     if (n == 0) return RN_OK;
     const int N = ctx->p.N;
     const int cam_stride = 12 * N + 12 + 4;
-    const float *P = cameras, *P_inv = cameras + 12 * N, *cc = cameras + 12 * N + 12;
-    {
-        ProfScope prof(ctx, RN_K_TRAVERSE, n * n_images, S(stream));
-        hipLaunchKernelGGL((k_traverse<true>), dim3((n + WAVE - 1) / WAVE, n_images), dim3(WAVE), 0,
-                           S(stream), ctx->p, n, ray_idxs, P_inv, cc, (const float *)nullptr,
-                           (const float *)nullptr, vox, rvc, cam_stride, rows_per_image,
-                           ray_segments);
+    const size_t M = (size_t)ctx->p.M;
+    // traverse + sweep of images [g0, g0 + ng); the traversal on `trav_st`, the sweep on `st`
+    auto traverse = [&](int g0, int ng, hipStream_t trav_st) {
+        const float *cam = cameras + (size_t)g0 * cam_stride;
+        const size_t row0 = (size_t)g0 * rows_per_image;
+        ProfScope prof(ctx, RN_K_TRAVERSE, n * ng, trav_st);
+        hipLaunchKernelGGL((k_traverse<true>), dim3((n + WAVE - 1) / WAVE, ng), dim3(WAVE), 0,
+                           trav_st, ctx->p, n, ray_idxs, cam + 12 * N, cam + 12 * N + 12,
+                           (const float *)nullptr, (const float *)nullptr, vox + row0 * M,
+                           rvc + row0, cam_stride, rows_per_image,
+                           ray_segments ? ray_segments + row0 * 8 : nullptr);
+    };
+    auto sweep = [&](int g0, int ng, hipStream_t st) {
+        const float *cam = cameras + (size_t)g0 * cam_stride;
+        const size_t row0 = (size_t)g0 * rows_per_image;
+        SweepArgs a{n, ray_idxs, FeatureViews{}, cam, cam + 12 * N, cam + 12 * N + 12, nullptr,
+                    nullptr, nullptr, vox + row0 * M, rvc + row0, nullptr, Sr + row0 * M, nullptr,
+                    nullptr};
+        a.order = order;
+        a.fv_table = features_views + (size_t)g0 * N;
+        a.cam_stride = cam_stride;
+        a.rows_per_image = rows_per_image;
+        a.n_images = ng;
+        a.seg = ray_segments ? ray_segments + row0 * 8 : nullptr;
+        launch_sweep<2, true>(ctx, a, true, st);
+    };
+    const int gA = ctx->overlap && n_images >= 2 && (int64_t)n * n_images >= 65536
+                       ? (n_images + 1) / 2 : n_images;
+    if (gA < n_images) {
+        // the thread-per-ray traversal (a chain of dependent fp32 additions per ray, few waves
+        // per CU) of the second half of the images hides under the plane sweep of the first
+        RN_HIP(ctx, hipEventRecord(ctx->ev_fork, S(stream)));
+        RN_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        traverse(0, gA, S(stream));
+        RN_LAUNCH_CHECK(ctx);
+        traverse(gA, n_images - gA, ctx->aux);
+        RN_LAUNCH_CHECK(ctx);
+        RN_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+        sweep(0, gA, S(stream));
+        RN_LAUNCH_CHECK(ctx);
+        RN_HIP(ctx, hipStreamWaitEvent(S(stream), ctx->ev_join, 0));
+        sweep(gA, n_images - gA, S(stream));
+        RN_LAUNCH_CHECK(ctx);
+    } else {
+        traverse(0, n_images, S(stream));
+        RN_LAUNCH_CHECK(ctx);
+        sweep(0, n_images, S(stream));
+        RN_LAUNCH_CHECK(ctx);
     }
-    RN_LAUNCH_CHECK(ctx);
-    SweepArgs a{n, ray_idxs, FeatureViews{}, P, P_inv, cc, nullptr, nullptr, nullptr, vox, rvc,
-                nullptr, Sr, nullptr, nullptr};
-    a.order = order;
-    a.fv_table = features_views;
-    a.cam_stride = cam_stride;
-    a.rows_per_image = rows_per_image;
-    a.n_images = n_images;
-    a.seg = ray_segments;
-    launch_sweep<2, true>(ctx, a, true, S(stream));
-    RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }
 

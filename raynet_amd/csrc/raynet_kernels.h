@@ -299,7 +299,14 @@ __device__ __forceinline__ float sweep_round(const float *const (&vbase)[NV], co
         }
         // byte offset from a uniform GLOBAL base: loads with a 32-bit register offset
         // (global_load ... s[base]), no 64-bit address arithmetic per lane
+        // -DRN_EXP_SWEEP_WINDOW=<mask>: timing experiment only (wrong results) -- every gather
+        // falls into a window of <mask>+1 bytes of its map: what the sweep costs when its
+        // feature vectors come from L1 (16 KB window) / from L2 (2 MB window)
+#ifdef RN_EXP_SWEEP_WINDOW
+        const unsigned ob = (((unsigned)__shfl(offb[v], src)) & (unsigned)(RN_EXP_SWEEP_WINDOW) & ~127u) + part_bytes;
+#else
         const unsigned ob = (unsigned)__shfl(offb[v], src) + part_bytes;
+#endif
         typedef const __attribute__((address_space(1))) char *gptr;
         typedef const __attribute__((address_space(1))) float4v *gptr4;
 #pragma unroll
@@ -407,8 +414,13 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             float point[3];
             plane_point(s, e, k, p.D, point);
 #pragma unroll
-            for (int v = 0; v < NV; v++)
+            for (int v = 0; v < NV; v++) {
+#ifdef RN_EXP_SWEEP_NOPROJ      // timing experiment only (wrong results): no projection arithmetic
+                offb[v] = (int)(((unsigned)(k * 977 + v * 131071 + lane * 8191) * 128u) & 0xffffffu);
+#else
                 offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, P + 12 * v, point, pad_shift);
+#endif
+            }
         }
         // View 0 is the reference image itself: every plane of the ray projects onto the
         // ray's own pixel there (up to the rounding of the projection, which is checked, not

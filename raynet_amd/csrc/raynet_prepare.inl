@@ -297,6 +297,9 @@ void k_sweep_map(
     }
     wave_sync();
     RN_PHASE_MARK(3);                      // softmax
+#ifdef RN_EXP_SWEEP_NOMAP       // timing experiment only (wrong results): no planes -> voxels
+    if (MAPMODE == 2) return;
+#endif
 
     if (MAPMODE == 0) {
         for (int k = lane; k < p.D; k += WAVE) S_planes[(size_t)r * p.D + k] = Sl[k];
