@@ -30,8 +30,10 @@ __device__ __forceinline__ int xcd_block(int b, int nblocks) {
 __device__ __forceinline__ int ray_of_wave(int n, int &lane) {
     lane = threadIdx.x & (WAVE - 1);
     const int b = xcd_block(blockIdx.x, gridDim.x);
-    const int r = b * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    return r < n ? uniform(r) : -1;
+    // the wave's ray index lives in an SGPR (the compiler cannot see that threadIdx.x >> 6 is
+    // wave-uniform): row addresses become scalar base + per-lane 32-bit offset
+    const int r = uniform(b * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    return r < n ? r : -1;
 }
 
 // ------------------------------------------------------------- small kernels

@@ -48,6 +48,21 @@ struct RayRows {
     float sv[NCH], mv[NCH];
     int pk[NCH];
 };
+// A ray's rows start at a wave-uniform address; element i of a row is addressed as that
+// uniform base + a 32-bit byte offset per lane (global_load_dword v, v_off, s[base:base+1]):
+// no 64-bit address arithmetic on the VALU, which is what these kernels are short of.
+typedef const __attribute__((address_space(1))) char *gbytes;
+template <typename T>
+__device__ __forceinline__ T row_load(const T *row_uniform, unsigned i) {
+    typedef const __attribute__((address_space(1))) T *gT;
+    return *(gT)((gbytes)row_uniform + i * (unsigned)sizeof(T));
+}
+template <typename T>
+__device__ __forceinline__ void row_store(T *row_uniform, unsigned i, T v) {
+    typedef __attribute__((address_space(1))) T *gT;
+    typedef __attribute__((address_space(1))) char *gb;
+    *(gT)((gb)row_uniform + i * (unsigned)sizeof(T)) = v;
+}
 // the first `count` entries of the ray's column, voxel list and (optionally) messages
 template <int NCH, bool PACKED>
 __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
@@ -67,11 +82,12 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
 #ifdef RN_EXP_NO_SR
             R.sv[ch] = 1.0f / count;
 #else
-            R.sv[ch] = Srow[i];
+            R.sv[ch] = row_load(Srow, (unsigned)i);
 #endif
-            R.pk[ch] = load_packed<PACKED>(vrow, i);
+            if (PACKED) R.pk[ch] = row_load(vrow, (unsigned)i);
+            else R.pk[ch] = load_packed<PACKED>(vrow, i);
 #ifndef RN_EXP_NO_MSG
-            if (mrow) R.mv[ch] = mrow[i];
+            if (mrow) R.mv[ch] = row_load(mrow, (unsigned)i);
 #endif
         }
     }
@@ -186,7 +202,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
                 const float pos = cex[ch] + tsv[ch];
                 const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
                 const float m = bp_log(pos) - bp_log(neg);
-                mout_row[i] = m;
+                row_store(mout_row, (unsigned)i, m);
             }
         }
     }
@@ -739,7 +755,7 @@ __device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int
         const int i = ch * WAVE + lane;
         if (ch * WAVE < count && i < count) {
             const float d = bp_div(wv[ch], wsum);
-            if (S_new) S_new[(size_t)r * p.M + i] = d;
+            if (S_new) row_store(S_new + (size_t)r * p.M, (unsigned)i, d);
             if (d > best) {   // ascending i per lane: keeps the first maximum
                 best = d;
                 best_i = i;
