@@ -200,6 +200,12 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
                          const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
                          float *Sr, float *ray_segments, void *stream);
 
+/* What the adaptive accumulator scatter of the resident path last saw (diagnostics): the tile
+ * shape in use (0: 128 rays x 32 steps, 1: 256 x 16, 2: slab scatter) and, of the most recent
+ * launch whose counters have arrived on the host, the number of tile chunks and how many of
+ * them did not fit the LDS box. */
+int rn_scatter_state(const rn_ctx *ctx, int32_t *level, uint32_t *chunks, uint32_t *overflowed);
+
 /* Voxel counts only (the traversal of rn_scene_prepare_all without its lists): rvc
  * [n_images][n] i32, row g*n + i = number of voxels ray ray_idxs[i] crosses in reference image
  * g (<= M).  The multi-GPU driver balances its ray shards by these counts (the cost of the BP

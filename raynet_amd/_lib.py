@@ -86,6 +86,8 @@ SIGNATURES = {
     "rn_scene_count_voxels": [_P, _I, _I, _P, _P, _P, _P],
     "rn_acc_copies": [_P],
     "rn_scatter_reset": [_P],
+    "rn_scatter_state": [_P, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_uint32),
+                         ctypes.POINTER(ctypes.c_uint32)],
     "rn_acc_size": [_P],
     "rn_acc_to_grid": [_P, _P, _P, _P],
     "rn_acc_from_grid": [_P, _P, _P, _P],

@@ -714,6 +714,14 @@ int rn_scatter_reset(rn_ctx *ctx) {
     return RN_OK;
 }
 
+int rn_scatter_state(const rn_ctx *ctx, int32_t *level, uint32_t *chunks, uint32_t *overflowed) {
+    if (!ctx || !level || !chunks || !overflowed) return RN_ERR_INVALID;
+    *level = ctx->box_level;
+    *chunks = ctx->box_stats_host[0];
+    *overflowed = ctx->box_stats_host[1];
+    return RN_OK;
+}
+
 int64_t rn_acc_size(const rn_ctx *ctx) { return ctx ? acc_floats(ctx) : 0; }
 
 int rn_acc_to_grid(rn_ctx *ctx, const float *acc, float *grid_out, void *stream) {

@@ -121,6 +121,13 @@ class HipContext(object):
     def scatter_reset(self):
         self._check(self.lib.rn_scatter_reset(self._h))
 
+    def scatter_state(self):
+        """-> (tile level in use, chunks, overflowed chunks of the last counted launch)"""
+        lv, ch, ov = ctypes.c_int32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.lib.rn_scatter_state(self._h, ctypes.byref(lv), ctypes.byref(ch),
+                                              ctypes.byref(ov)))
+        return int(lv.value), int(ch.value), int(ov.value)
+
     # resident accumulators are 4x4x4-bricked (include/raynet_hip.h); the reference's
     # [gx][gy][gz] view is produced / consumed through these two
     def acc_size(self):

@@ -53,10 +53,16 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
         ctx.prof_begin(capacity=1024)
         t0 = time.perf_counter()
         n = 20
+        per_step = []
         for _ in range(n):
+            t1 = time.perf_counter()
             step()
+            per_step.append((time.perf_counter() - t1) * 1e3)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
+        if max(per_step) > 2 * float(np.median(per_step)):
+            print("   (step times ms: median %.3f max %.3f at step %d)" % (
+                float(np.median(per_step)), max(per_step), int(np.argmax(per_step))))
         fam = {}
         launches = ctx.prof_end()
         for name, _, k_ms in launches:
@@ -68,8 +74,9 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
                 print("   %-10s start %8.3f  gap %7.3f  dur %7.3f" % (name, st, st - end_prev, k_ms))
                 end_prev = st + k_ms
         res[(world, rank)] = ms
-        print("world %d rank %d: %.3f ms/step  kernels %.3f  (%s)" % (
-            world, rank, ms, sum(fam.values()), " ".join("%s=%.3f" % kv for kv in sorted(fam.items()))))
+        print("world %d rank %d: %.3f ms/step  kernels %.3f  (%s)  scatter level/chunks/overflowed %s" % (
+            world, rank, ms, sum(fam.values()), " ".join("%s=%.3f" % kv for kv in sorted(fam.items())),
+            ctx.scatter_state()))
         if fp.shard_balance is not None and rank == 0:
             bal = np.array(fp.shard_balance, dtype=np.float64).sum(0)
             rows = [fp._plan["bounds"][0][q + 1] - fp._plan["bounds"][0][q] for q in range(world)]
