@@ -25,6 +25,18 @@
  *   cuda_implementations/mrf_bp.cu:37-86 + mrf/mrf_np.py:333-385  -> rno_depth_ray
  *   cuda_implementations/raynet_fp.py:55-227            -> rno_fused_bp / rno_fused_depth
  *
+ * How each piece is pinned to the reference (tests/test_oracle_golden.py,
+ * tests/test_sampling_reference.py, tests/test_saturated_golden.py):
+ *   rno_sample_in_bbox    the reference's NumPy sampling scheme on 11 cameras (1.1e-6)
+ *   rno_voxel_traversal   the reference's compiled Cython traversal (bit-exact)
+ *   rno_planes_to_voxels  the reference's NumPy `li` / `li_2` mappings
+ *   rno_bp_ray / rno_depth_ray   the reference's mrf_np.py, both message forms on the small
+ *                         scenes; the robust form on the saturated 96,000-ray scene
+ *   rno_similarities      PARITY UNPINNED: the reference has only a PyCUDA and a TensorFlow
+ *                         implementation of the plane sweep, neither runnable here, and no
+ *                         test of it; cross-checked against the .cu text run on the host
+ *   rno_fused_bp / _depth compositions of the above
+ *
  * Decisions where the reference's flavours disagree:
  *   Q3  the D-plane column is zero-initialised before accumulation;
  *   Q4  rays with count <= 1 send no message and get an all-zero distribution
