@@ -18,7 +18,15 @@ def _stream():
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    """Raw device pointer of a tensor for the C ABI (NULL for None).  Every pointer handed to
+    the library goes through here: it must be a contiguous CUDA tensor -- a strided view or a
+    host tensor would be read as something else, silently."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("the C ABI takes contiguous CUDA tensors (got %s, %s)" % (
+            "cuda" if t.is_cuda else "cpu", "contiguous" if t.is_contiguous() else "strided"))
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _chk(t, dtype, min_numel=0, name="tensor", optional=False, align=16):
@@ -154,28 +162,50 @@ class HipContext(object):
         return float(ms.value)
 
     # ---- differentiable MRF block (training) -----------------------------------------
+    def _chk_api_rows(self, rvi, rvc, *float_rows):
+        """K-API layouts: rvi [n][M][3] i32, rvc [n] i32, float rows [n][M] f32."""
+        n = len(rvc)
+        _chk(rvi, torch.int32, n * self.M * 3, "ray_voxel_indices")
+        _chk(rvc, torch.int32, n, "ray_voxel_count")
+        for k, t in enumerate(float_rows):
+            _chk(t, torch.float32, n * self.M, "row array %d" % k, optional=True)
+        return n
+
     def plane_weights(self, rvi, rvc, starts, ends, left, c1, c2):
+        n = self._chk_api_rows(rvi, rvc, c1, c2)
+        _chk(left, torch.int32, n * self.M, "left")
+        _chk(starts, torch.float32, 3 * n, "starts", align=4)
+        _chk(ends, torch.float32, 3 * n, "ends", align=4)
         self._check(self.lib.rn_plane_weights(self._h, len(rvc), _ptr(rvi), _ptr(rvc), _ptr(starts),
                                               _ptr(ends), _ptr(left), _ptr(c1), _ptr(c2),
                                               _stream()))
 
     def train_bp_sweep(self, Sr, rvi, rvc, acc_in, msgs_in, acc_out, msgs_out):
+        self._chk_api_rows(rvi, rvc, Sr, msgs_in, msgs_out)
+        _chk(acc_in, torch.float32, self.G, "acc_in"); _chk(acc_out, torch.float32, self.G, "acc_out")
         self._check(self.lib.rn_train_bp_sweep(self._h, len(rvc), _ptr(Sr), _ptr(rvi), _ptr(rvc),
                                                _ptr(acc_in), _ptr(msgs_in), _ptr(acc_out),
                                                _ptr(msgs_out), _stream()))
 
     def train_depth(self, Sr, rvi, rvc, acc, msgs, S_new):
+        self._chk_api_rows(rvi, rvc, Sr, msgs, S_new)
+        _chk(acc, torch.float32, self.G, "acc")
         self._check(self.lib.rn_train_depth(self._h, len(rvc), _ptr(Sr), _ptr(rvi), _ptr(rvc),
                                             _ptr(acc), _ptr(msgs), _ptr(S_new), _stream()))
 
     def train_bp_sweep_bwd(self, Sr, rvi, rvc, acc_in, msgs_in, g_msgs_out, g_acc_out, g_Sr,
                            g_acc_in, g_msgs_in):
+        self._chk_api_rows(rvi, rvc, Sr, msgs_in, g_msgs_out, g_Sr, g_msgs_in)
+        for name, t in (("acc_in", acc_in), ("g_acc_out", g_acc_out), ("g_acc_in", g_acc_in)):
+            _chk(t, torch.float32, self.G, name)
         self._check(self.lib.rn_train_bp_sweep_bwd(
             self._h, len(rvc), _ptr(Sr), _ptr(rvi), _ptr(rvc), _ptr(acc_in), _ptr(msgs_in),
             _ptr(g_msgs_out), _ptr(g_acc_out), _ptr(g_Sr), _ptr(g_acc_in), _ptr(g_msgs_in),
             _stream()))
 
     def train_depth_bwd(self, Sr, rvi, rvc, acc, msgs, g_S_new, g_Sr, g_acc, g_msgs):
+        self._chk_api_rows(rvi, rvc, Sr, msgs, g_S_new, g_Sr, g_msgs)
+        _chk(acc, torch.float32, self.G, "acc"); _chk(g_acc, torch.float32, self.G, "g_acc")
         self._check(self.lib.rn_train_depth_bwd(
             self._h, len(rvc), _ptr(Sr), _ptr(rvi), _ptr(rvc), _ptr(acc), _ptr(msgs),
             _ptr(g_S_new), _ptr(g_Sr), _ptr(g_acc), _ptr(g_msgs), _stream()))
