@@ -38,8 +38,13 @@ __global__ void k_sample_points(Params p, int n, const int32_t *__restrict__ ray
 // camera (sample_in_bbox), as in the fused kernels.
 // A thread writing its own row step by step produces one partial-line write per voxel
 // (4x write amplification measured).  Each 64-thread block therefore collects
-// [64 rays][TRAV_TILE steps] in LDS and writes finished tiles as coalesced row segments.
-constexpr int TRAV_TILE = 32;
+// [64 rays][TRAV_TILE steps] in LDS and writes finished tiles as coalesced row segments
+// (16 steps: 0.42 ms per scene against 0.46 at 32 and 0.70 at 64 -- the tile's LDS decides how
+// many of these serial, latency-bound threads a CU holds).
+#ifndef RN_TRAV_TILE
+#define RN_TRAV_TILE 16
+#endif
+constexpr int TRAV_TILE = RN_TRAV_TILE;     // steps collected per flush: 16, 32 or 64
 template <bool PACKED>
 __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                                                    const int32_t *__restrict__ ray_idxs,
@@ -199,12 +204,14 @@ __device__ unsigned long long g_phase[16];
 #define RN_PHASE_DECL
 #define RN_PHASE_MARK(K)
 #endif
-// waves per SIMD the register allocation has to leave room for: 7 (<= 72 VGPRs; the kernel
-// needs 74 unconstrained) measured -1.8 % on the 5-view sweep, 8 (64 VGPRs) -0.5 %; the
-// wide sweeps (two load rounds of 7+ views do not fit), the reference-layout variants and
-// the 4-view sweep (which would spill) are left alone
+// waves per SIMD the register allocation has to leave room for.  Round 1: 7 (<= 72 VGPRs; the
+// kernel needs 74 unconstrained) -1.8 % on the 5-view sweep, 8 (64 VGPRs) -0.5 %.  Round 2
+// (profiles/r02_exp_knobs.txt, after the ray index moved to an SGPR and rays without voxels
+// stopped sweeping): 6 is best -- 2.80 ms against 2.91 at 7, 2.81 at 5, 2.84 at 4, 3.02 at 8.
+// The wide sweeps (two load rounds of 7+ views do not fit), the reference-layout variants
+// and the 4-view sweep (which would spill) are left alone
 #ifndef RN_SWEEP_MIN_WAVES
-#define RN_SWEEP_MIN_WAVES 7
+#define RN_SWEEP_MIN_WAVES 6
 #endif
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
 __global__ __launch_bounds__(BLOCK, (SIM == 2 && MAPMODE == 2 && NV >= 5 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
