@@ -200,6 +200,21 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
                          const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
                          float *Sr, float *ray_segments, void *stream);
 
+/* Slab boxes (optional).  The accumulator scatter of RN_ROWS_PATCHES rows sums a tile's
+ * messages in an LDS image of the bounding box of the voxels the tile's rays visit in a chunk
+ * of steps.  That box depends on the rays alone, not on the messages: bound to a list buffer,
+ * rn_scene_prepare_all leaves, per 64 consecutive rows and per 16 steps, the box of the voxels
+ * those rays visit there (a DDA is monotone along every axis: the extremes are the first and
+ * the last voxel), and the three scatters of a pass merge boxes instead of scanning the lists.
+ *   vox    the buffer rn_scene_prepare_all writes its lists to ([rows][M] i32)
+ *   boxes  rn_slab_boxes_size(rows) i32 of scratch owned by the caller
+ * Contract: while bound, the rows of `vox` are written by rn_scene_prepare_all only
+ * (rn_scene_prepare into the buffer switches the table off until the next prepare_all);
+ * rn_scene_bp_sweep* use the table for list pointers inside `vox` whose rows it covers, and
+ * scan the lists as before for any other pointer.  boxes == NULL unbinds. */
+int64_t rn_slab_boxes_size(const rn_ctx *ctx, int64_t rows);
+int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int32_t *boxes);
+
 /* What the adaptive accumulator scatter of the resident path last saw (diagnostics): the tile
  * shape in use (0: 128 rays x 32 steps, 1: 256 x 16, 2: slab scatter) and, of the most recent
  * launch whose counters have arrived on the host, the number of tile chunks and how many of

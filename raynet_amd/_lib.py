@@ -86,6 +86,8 @@ SIGNATURES = {
     "rn_scene_count_voxels": [_P, _I, _I, _P, _P, _P, _P],
     "rn_acc_copies": [_P],
     "rn_scatter_reset": [_P],
+    "rn_slab_boxes_size": [_P, _L],
+    "rn_scene_bind_slab_boxes": [_P, _P, _L, _P],
     "rn_scatter_state": [_P, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_uint32),
                          ctypes.POINTER(ctypes.c_uint32)],
     "rn_acc_size": [_P],
@@ -139,5 +141,6 @@ def load():
     lib.rn_last_error.restype = ctypes.c_char_p
     lib.rn_version.restype = ctypes.c_char_p
     lib.rn_acc_size.restype = ctypes.c_int64
+    lib.rn_slab_boxes_size.restype = ctypes.c_int64
     _lib = lib
     return lib

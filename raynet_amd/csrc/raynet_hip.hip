@@ -120,6 +120,11 @@ struct rn_ctx {
     // Measured (profiles/r02_exp_overlap.txt): config 2 8.72 -> 8.84 ms/step (either kernel
     // alone already keeps the VALUs of every CU busy), config 4 44.3 -> 42.5 (its scatter
     // waits on L2 atomics: 3.9 hits per voxel)
+    // slab boxes (rn_scene_bind_slab_boxes): table, the list buffer it describes, and the row
+    // range rn_scene_prepare_all last filled
+    const int32_t *sb_vox;
+    int64_t sb_rows, sb_valid_lo, sb_valid_hi;
+    int2 *sb_boxes;
     bool overlap;
     hipStream_t aux;
     hipEvent_t ev_fork, ev_join;
@@ -242,6 +247,17 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
     launch_sweep_t<1, 1, 8, MAPMODE, PACKED>(ctx, a, st);
 }
 
+// the slab-box rows that describe `vox` (a pointer into the bound list buffer), or null
+inline int2 *slab_boxes_for(const rn_ctx *ctx, const int32_t *vox, int64_t n, bool need_valid) {
+    if (!ctx->sb_boxes || !vox || vox < ctx->sb_vox) return nullptr;
+    const int64_t off = vox - ctx->sb_vox;
+    if (off % ctx->p.M) return nullptr;
+    const int64_t row0 = off / ctx->p.M;
+    if (row0 % WAVE || row0 + n > ctx->sb_rows) return nullptr;
+    if (need_valid && (row0 < ctx->sb_valid_lo || row0 + n > ctx->sb_valid_hi)) return nullptr;
+    return ctx->sb_boxes + (row0 / WAVE) * slab_box_count(ctx->p.M);
+}
+
 // workgroups per box-scatter tile (grid.y): enough of them for ~16 per CU
 inline int box_split(int n, int tile_rays) {
     const int tiles = (n + tile_rays - 1) / tile_rays;
@@ -277,7 +293,8 @@ void launch_scatter_kernel(rn_ctx *ctx, int n, const float *msgs, const int32_t 
     hipLaunchKernelGGL((k_scatter_box<PACKED, RAYS, STEPS, FIXED_>),                              \
                        dim3((n + RAYS - 1) / RAYS, box_split(n, RAYS)), dim3(BLOCK),              \
                        (CAP) * sizeof(double), st, ctx->p, n, msgs, vox, rvc, acc_out,            \
-                       ctx->box_stats, CAP)
+                       ctx->box_stats, CAP,                                                       \
+                       (const int2 *)(PACKED ? slab_boxes_for(ctx, vox, n, true) : nullptr))
     if (level == 0) {
         if (fixed) RN_BOX(128, 32, true, 4096); else RN_BOX(128, 32, false, 4096);
     } else if (level == 1) {
@@ -714,6 +731,19 @@ int rn_scatter_reset(rn_ctx *ctx) {
     return RN_OK;
 }
 
+int64_t rn_slab_boxes_size(const rn_ctx *ctx, int64_t rows) {
+    return ctx && rows >= 0 ? ((rows + WAVE - 1) / WAVE) * slab_box_count(ctx->p.M) * 2 : 0;
+}
+
+int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int32_t *boxes) {
+    if (!ctx || rows < 0 || (boxes && !vox)) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    ctx->sb_vox = boxes ? vox : nullptr;
+    ctx->sb_rows = boxes ? rows : 0;
+    ctx->sb_boxes = reinterpret_cast<int2 *>(boxes);
+    ctx->sb_valid_lo = ctx->sb_valid_hi = 0;
+    return RN_OK;
+}
+
 int rn_scatter_state(const rn_ctx *ctx, int32_t *level, uint32_t *chunks, uint32_t *overflowed) {
     if (!ctx || !level || !chunks || !overflowed) return RN_ERR_INVALID;
     *level = ctx->box_level;
@@ -753,6 +783,8 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
     int rc = need_axes(ctx);
     if (rc) return rc;
     if (n == 0) return RN_OK;
+    if (ctx->sb_boxes && vox >= ctx->sb_vox && vox < ctx->sb_vox + ctx->sb_rows * (int64_t)ctx->p.M)
+        ctx->sb_valid_lo = ctx->sb_valid_hi = 0;      // this entry does not maintain slab boxes
     FeatureViews fv;
     for (int v = 0; v < MAX_VIEWS; v++) fv.v[v] = v < ctx->p.N ? features_views_host[v] : nullptr;
     for (int v = 0; v < ctx->p.N; v++)
@@ -786,6 +818,18 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
     const int N = ctx->p.N;
     const int cam_stride = 12 * N + 12 + 4;
     const size_t M = (size_t)ctx->p.M;
+    // slab boxes for the scatter, when a table is bound to this list buffer (rows_per_image is
+    // then a multiple of 64 by the binding's contract: checked)
+    int2 *boxes = rows_per_image % WAVE == 0
+                      ? slab_boxes_for(ctx, vox, (int64_t)n_images * rows_per_image, false) : nullptr;
+    if (ctx->sb_boxes && vox >= ctx->sb_vox && vox < ctx->sb_vox + ctx->sb_rows * (int64_t)M) {
+        if (boxes) {
+            ctx->sb_valid_lo = (vox - ctx->sb_vox) / (int64_t)M;
+            ctx->sb_valid_hi = ctx->sb_valid_lo + (int64_t)n_images * rows_per_image;
+        } else {
+            ctx->sb_valid_lo = ctx->sb_valid_hi = 0;
+        }
+    }
     // traverse + sweep of images [g0, g0 + ng); the traversal on `trav_st`, the sweep on `st`
     auto traverse = [&](int g0, int ng, hipStream_t trav_st) {
         const float *cam = cameras + (size_t)g0 * cam_stride;
@@ -795,7 +839,8 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
                            trav_st, ctx->p, n, ray_idxs, cam + 12 * N, cam + 12 * N + 12,
                            (const float *)nullptr, (const float *)nullptr, vox + row0 * M,
                            rvc + row0, cam_stride, rows_per_image,
-                           ray_segments ? ray_segments + row0 * 8 : nullptr);
+                           ray_segments ? ray_segments + row0 * 8 : nullptr,
+                           boxes ? boxes + (row0 / WAVE) * slab_box_count(ctx->p.M) : nullptr);
     };
     auto sweep = [&](int g0, int ng, hipStream_t st) {
         const float *cam = cameras + (size_t)g0 * cam_stride;

@@ -509,6 +509,13 @@ __device__ __forceinline__ int pack_voxel(int x, int y, int z) {
     return (x << 20) | (y << 10) | z;
 }
 
+// Slab boxes: per block of 64 consecutive rows and per 16 steps, the bounding box of the
+// voxels those rays visit there (k_traverse writes them, k_scatter_box merges them).
+constexpr int SLAB_BOX_STEPS = 16;
+__host__ __device__ __forceinline__ int slab_box_count(int M) {
+    return (M + SLAB_BOX_STEPS - 1) / SLAB_BOX_STEPS;
+}
+
 // ------------------------------------------------------------------- a4
 // planes_voxels_mapping.cu:6-92 for one ray, wave-parallel.
 //   * t_i is computed per lane;

@@ -499,7 +499,8 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                                        const int32_t *__restrict__ vox,
                                                        const int32_t *__restrict__ rvc,
                                                        void *acc_out_raw,
-                                                       unsigned *overflow_stats, int BOX_CAP) {
+                                                       unsigned *overflow_stats, int BOX_CAP,
+                                                       const int2 *__restrict__ slab_boxes) {
     typedef AccSum<FIXED> Sum;
     typename Sum::acc_t *acc_out = static_cast<typename Sum::acc_t *>(acc_out_raw);
     constexpr int BOX_NB = BOX_RAYS * BOX_STEPS / BLOCK;     // pairs per thread and chunk
@@ -527,10 +528,18 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
     maxc = wave_reduce_max(maxc);
     if (lane == 0) red_cnt[w] = maxc;
     __syncthreads();
+    // longest sending ray of every 64-row half (wave w loaded rows 64 w ... 64 w + 63 above:
+    // BOX_RAYS <= BLOCK): the slabs the traversal certainly wrote for that half
+    int half_true[(BOX_RAYS + WAVE - 1) / WAVE];
+#pragma unroll
+    for (int hb = 0; hb < (BOX_RAYS + WAVE - 1) / WAVE; hb++) half_true[hb] = uniform(red_cnt[hb]);
 #pragma unroll
     for (int k = 0; k < WAVES_PER_BLOCK; k++) maxc = max(maxc, red_cnt[k]);
     maxc = uniform(maxc);
 
+    // the LDS box is zero whenever a chunk starts: zeroed once here, and every flush clears
+    // what it read (no zero pass and one barrier less per chunk)
+    for (int i = tid; i < BOX_CAP; i += BLOCK) box[i] = 0;
     int it = 0;
     // per-thread partial bounding box -> the workgroup's (uniform)
     auto block_bbox = [&](int &lo0, int &lo1, int &lo2, int &hi0, int &hi1, int &hi2) {
@@ -562,7 +571,13 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
         const int sz = BLOCK % d2, ty = BLOCK / d2;
         const int sy = ty % d1, sx = ty / d1;
         for (int i = tid; i < V; i += BLOCK) {
-            Sum::flush(acc_out, lin_xyz<PACKED>(p, lo0 + i0, lo1 + i1, lo2 + i2), box[i]);
+            const typename Sum::box_t bv = box[i];
+            box[i] = 0;                 // the box is all zero again when the next chunk starts
+#ifdef RN_EXP_BOX_NOFLUSH       // timing experiment only (wrong results): no global atomics
+            asm volatile("" ::"v"(bv));
+#else
+            Sum::flush(acc_out, lin_xyz<PACKED>(p, lo0 + i0, lo1 + i1, lo2 + i2), bv);
+#endif
             i2 += sz;
             if (i2 >= d2) { i2 -= d2; i1++; }
             i1 += sy;
@@ -592,16 +607,43 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             v[k] = load_packed<PACKED>(vox + (size_t)rr * p.M * (PACKED ? 1 : 3), ss);
         }
         int lo0 = 1 << 30, lo1 = 1 << 30, lo2 = 1 << 30, hi0 = -1, hi1 = -1, hi2 = -1;
+        if (slab_boxes) {
+            // the traversal left the box of every (64 rows, 16 steps) slab: merge the tile's
+            // (wave-uniform loads; a 64-row half is read only up to ITS longest ray -- slabs
+            // beyond that were never written)
+            constexpr int HB = (BOX_RAYS + WAVE - 1) / WAVE, SL = BOX_STEPS / SLAB_BOX_STEPS;
+            const int nsl = slab_box_count(p.M);
+            const int2 *tb = slab_boxes + (size_t)(r0 / WAVE) * nsl + s0 / SLAB_BOX_STEPS;
 #pragma unroll
-        for (int k = 0; k < BOX_NB; k++) {
-            if (okmask >> k & 1) {
-                const int x = v[k] >> 20, y = (v[k] >> 10) & 1023, z = v[k] & 1023;
-                lo0 = min(lo0, x); hi0 = max(hi0, x);
-                lo1 = min(lo1, y); hi1 = max(hi1, y);
-                lo2 = min(lo2, z); hi2 = max(hi2, z);
+            for (int hb = 0; hb < HB; hb++) {
+#pragma unroll
+                for (int sl = 0; sl < SL; sl++) {
+                    if (s0 + sl * SLAB_BOX_STEPS < half_true[hb]) {
+                        const int2 bx = tb[(size_t)hb * nsl + sl];
+                        lo0 = min(lo0, bx.x >> 20); lo1 = min(lo1, (bx.x >> 10) & 1023);
+                        lo2 = min(lo2, bx.x & 1023);
+                        if (bx.y >= 0) {
+                            hi0 = max(hi0, bx.y >> 20); hi1 = max(hi1, (bx.y >> 10) & 1023);
+                            hi2 = max(hi2, bx.y & 1023);
+                        }
+                    }
+                }
             }
+            lo0 = uniform(lo0); lo1 = uniform(lo1); lo2 = uniform(lo2);
+            hi0 = uniform(hi0); hi1 = uniform(hi1); hi2 = uniform(hi2);
+            __syncthreads();          // every thread has finished the previous flush
+        } else {
+#pragma unroll
+            for (int k = 0; k < BOX_NB; k++) {
+                if (okmask >> k & 1) {
+                    const int x = v[k] >> 20, y = (v[k] >> 10) & 1023, z = v[k] & 1023;
+                    lo0 = min(lo0, x); hi0 = max(hi0, x);
+                    lo1 = min(lo1, y); hi1 = max(hi1, y);
+                    lo2 = min(lo2, z); hi2 = max(hi2, z);
+                }
+            }
+            block_bbox(lo0, lo1, lo2, hi0, hi1, hi2);
         }
-        block_bbox(lo0, lo1, lo2, hi0, hi1, hi2);
         if (hi0 < 0) continue;        // (cannot happen below maxc; uniform anyway)
         const int d0 = hi0 - lo0 + 1, d1 = hi1 - lo1 + 1, d2 = hi2 - lo2 + 1;
         const int V = d0 * d1 * d2;
@@ -613,15 +655,17 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
         }
 #endif
         if (V <= BOX_CAP) {
-            for (int i = tid; i < V; i += BLOCK) box[i] = 0;
-            __syncthreads();
 #pragma unroll
             for (int k = 0; k < BOX_NB; k++)
                 if (okmask >> k & 1) {
                     const int x = v[k] >> 20, y = (v[k] >> 10) & 1023, z = v[k] & 1023;
+#ifdef RN_EXP_BOX_NOLDS         // timing experiment only (wrong results): no LDS atomics
+                    asm volatile("" ::"v"(((x - lo0) * d1 + (y - lo1)) * d2 + (z - lo2)), "v"(m[k]));
+#else
                     __hip_atomic_fetch_add(box + ((x - lo0) * d1 + (y - lo1)) * d2 + (z - lo2),
                                            Sum::from_msg(m[k]), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                 }
             __syncthreads();
             flush_box(lo0, lo1, lo2, d0, d1, d2);
@@ -652,10 +696,6 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             if (hi0 < 0) continue;
             const int e0 = hi0 - lo0 + 1, e1 = hi1 - lo1 + 1, e2 = hi2 - lo2 + 1;
             const bool fits = e0 * e1 * e2 <= BOX_CAP;
-            if (fits) {
-                for (int i = tid; i < e0 * e1 * e2; i += BLOCK) box[i] = 0;
-                __syncthreads();
-            }
 #pragma unroll 1
             for (int k = 0; k < BOX_NB; k++) {
                 const int j = j0 + k * STRIDE;

@@ -53,7 +53,9 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                                                    const float *__restrict__ starts,
                                                    const float *__restrict__ ends, int32_t *vox,
                                                    int32_t *rvc, int cam_stride,
-                                                   int64_t rows_per_image, float *seg_out) {
+                                                   int64_t rows_per_image, float *seg_out,
+                                                   int2 *slab_boxes = nullptr) {
+    static_assert(TRAV_TILE == SLAB_BOX_STEPS || !PACKED, "slab boxes are per flushed tile");
     __shared__ int32_t tile[WAVE * (TRAV_TILE + 1)];
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * WAVE;
@@ -64,7 +66,9 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
         if (vox) vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
         rvc += (size_t)g * rows_per_image;
         if (seg_out) seg_out += (size_t)g * rows_per_image * 8;
+        if (slab_boxes) slab_boxes += (size_t)g * (rows_per_image / WAVE) * slab_box_count(p.M);
     }
+    if (slab_boxes) slab_boxes += (size_t)blockIdx.x * slab_box_count(p.M);
     const int r = r0 + lane;
     const bool live = r < n;
     float s[3] = {0.f, 0.f, 0.f}, e[3] = {0.f, 0.f, 0.f};
@@ -158,6 +162,28 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
         }
         if (!vox) continue;          // count-only launch (rn_scene_count_voxels): nothing to flush
         wave_sync();
+        // Bounding box of the voxels these 64 rays emitted in this slab of steps, for the
+        // accumulator scatter (k_scatter_box), which otherwise rebuilds it from the lists in
+        // every BP iteration.  A DDA moves monotonically along every axis, so a ray's extreme
+        // coordinates within the slab are those of its first and its last voxel there.
+        if (PACKED && slab_boxes) {
+            const int emitted = min(max(count - base, 0), TRAV_TILE);
+            int lo0 = 1 << 30, lo1 = 1 << 30, lo2 = 1 << 30, hi0 = -1, hi1 = -1, hi2 = -1;
+            if (emitted > 0) {
+                const int a = tile[lane * (TRAV_TILE + 1)];
+                const int b = tile[lane * (TRAV_TILE + 1) + emitted - 1];
+                const int ax = a >> 20, ay = (a >> 10) & 1023, az = a & 1023;
+                const int bx = b >> 20, by = (b >> 10) & 1023, bz = b & 1023;
+                lo0 = min(ax, bx); hi0 = max(ax, bx);
+                lo1 = min(ay, by); hi1 = max(ay, by);
+                lo2 = min(az, bz); hi2 = max(az, bz);
+            }
+            lo0 = wave_min_i(lo0); lo1 = wave_min_i(lo1); lo2 = wave_min_i(lo2);
+            hi0 = wave_max_i(hi0); hi1 = wave_max_i(hi1); hi2 = wave_max_i(hi2);
+            if (lane == 0)      // an empty slab (hi < lo) never reaches the scatter's merge
+                slab_boxes[base / TRAV_TILE] = make_int2(hi0 < 0 ? 0x7fffffff : pack_voxel(lo0, lo1, lo2),
+                                                         hi0 < 0 ? -1 : pack_voxel(hi0, hi1, hi2));
+        }
         // flush: TRAV_TILE consecutive steps of one ray are one contiguous segment
         constexpr int RPI = WAVE / TRAV_TILE;      // rows per instruction
 #pragma unroll 4

@@ -521,6 +521,8 @@ class RayNetForwardPass(ForwardPass):
         Vg = V if budget <= 0 else int(max(1, min(V, (budget - fixed) // (2 * per_image))))
         groups = [list(range(g, min(g + Vg, V))) for g in range(0, V, Vg)] if V else []
         self._plan = plan = None                     # release the old buffers first
+        if hasattr(ctx, "bind_slab_boxes"):
+            ctx.bind_slab_boxes(None)                # (the binding holds the old list buffer)
         rows_g = Vg * npad
         fixed_pt = self.deterministic and hasattr(ctx, "scene_bp_sweep_fixed")
         prior = self._prior()
@@ -552,6 +554,8 @@ class RayNetForwardPass(ForwardPass):
                                 rvc=plan["rvc"][row0:row0 + n], msgs=plan["msgs"][row0:row0 + n],
                                 depth=plan["depth"][row0:row0 + n])
         plan["per_image"] = per_image
+        if hasattr(ctx, "bind_slab_boxes") and os.environ.get("RAYNET_SLAB_BOXES", "1") != "0":
+            ctx.bind_slab_boxes(plan["vox"])      # the scatters merge boxes the traversal left
         if not self._filter_out_rays:
             self._plan = plan
         return plan

@@ -129,6 +129,21 @@ class HipContext(object):
     def scatter_reset(self):
         self._check(self.lib.rn_scatter_reset(self._h))
 
+    def bind_slab_boxes(self, vox):
+        """Let rn_scene_prepare_all keep slab boxes for the list buffer `vox` ([rows][M] i32;
+        None unbinds): the scatters of a pass then merge boxes instead of scanning the lists
+        (include/raynet_hip.h).  The scratch table lives with the context."""
+        if vox is None:
+            self._check(self.lib.rn_scene_bind_slab_boxes(self._h, None, 0, None))
+            self._slab_boxes = None
+            return
+        _chk(vox, torch.int32, self.M, "vox")
+        rows = vox.numel() // self.M
+        size = int(self.lib.rn_slab_boxes_size(self._h, rows))
+        self._slab_boxes = (torch.empty((size,), dtype=torch.int32, device=self.device), vox)
+        self._check(self.lib.rn_scene_bind_slab_boxes(self._h, _ptr(vox), rows,
+                                                      _ptr(self._slab_boxes[0])))
+
     def scatter_state(self):
         """-> (tile level in use, chunks, overflowed chunks of the last counted launch)"""
         lv, ch, ov = ctypes.c_int32(), ctypes.c_uint32(), ctypes.c_uint32()
