@@ -295,8 +295,11 @@ void launch_scatter_kernel(rn_ctx *ctx, int n, const float *msgs, const int32_t 
                        (CAP) * sizeof(double), st, ctx->p, n, msgs, vox, rvc, acc_out,            \
                        ctx->box_stats, CAP,                                                       \
                        (const int2 *)(PACKED ? slab_boxes_for(ctx, vox, n, true) : nullptr))
+#ifndef RN_BOX0_CAP
+#define RN_BOX0_CAP 4096
+#endif
     if (level == 0) {
-        if (fixed) RN_BOX(128, 32, true, 4096); else RN_BOX(128, 32, false, 4096);
+        if (fixed) RN_BOX(128, 32, true, RN_BOX0_CAP); else RN_BOX(128, 32, false, RN_BOX0_CAP);
     } else if (level == 1) {
         if (fixed) RN_BOX(256, 16, true, 6144); else RN_BOX(256, 16, false, 6144);
     } else if (fixed) {

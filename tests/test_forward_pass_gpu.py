@@ -713,3 +713,33 @@ def test_config4_full_size_properties_and_subset_parity(torch, oracle_mod):
         assert flips <= 0.01 * V * 300
     finally:
         oracle_mod.Oracle.set_robust_messages(False)
+
+
+def test_slab_boxes_and_second_stream_change_nothing(torch, monkeypatch):
+    """The scatter's bounding boxes taken from the traversal's slab boxes
+    (rn_scene_bind_slab_boxes) instead of from the lists, and the two-stream launchers
+    (RAYNET_HIP_OVERLAP=1): schedule and bookkeeping only -- in fixed-point mode the
+    accumulator and the depth maps are the same bits."""
+    import raynet_amd.hip_implementations as hi
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W = 96, 128          # 12288 rays per image: above the launchers' split threshold
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(32, 192, (64, 64, 64))
+    runs = {}
+    for slab, overlap in (("1", "0"), ("0", "0"), ("1", "1"), ("0", "1")):
+        monkeypatch.setenv("RAYNET_SLAB_BOXES", slab)
+        monkeypatch.setenv("RAYNET_HIP_OVERLAP", overlap)
+        hi._CONTEXTS.clear()            # RAYNET_HIP_OVERLAP is read when a context is created
+        fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0,
+                                                deterministic=True)
+        d = np.stack(list(fp.forward_pass(scene, (0, 5, 1))))
+        d2 = np.stack(list(fp.forward_pass(scene, (0, 5, 1))))          # cached plan
+        assert np.array_equal(d, d2)
+        runs[(slab, overlap)] = (d, fp.accumulator.cpu().numpy(), fp._ctx.scatter_state()[0])
+        del fp
+    hi._CONTEXTS.clear()
+    ref = runs[("0", "0")]
+    assert ref[2] in (0, 1)             # the LDS-box scatter is what ran
+    for key, (d, acc, _) in runs.items():
+        assert np.array_equal(acc, ref[1]) and np.array_equal(d, ref[0]), key
