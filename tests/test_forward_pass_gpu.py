@@ -723,7 +723,7 @@ def test_slab_boxes_and_second_stream_change_nothing(torch, monkeypatch):
     import raynet_amd.hip_implementations as hi
     from raynet_amd.forward_pass import get_forward_pass_factory
     from raynet_amd.synthetic import make_synthetic_scene
-    H, W = 96, 128          # 12288 rays per image: above the launchers' split threshold
+    H, W = 112, 128         # 5 x 14336 rows: above the launchers' 65536-row split threshold
     scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
     gp = _gp(32, 192, (64, 64, 64))
     runs = {}
