@@ -566,7 +566,14 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
             vd -= s[2];
             sum += ray[2] * vd;
             t = clampf(sum / ray_norm, eps, 1 - eps);
-            L = max(0, (int)(t * (p.D - 1)) - 2);
+            // The walk's answer L* is the first L at which (t - L*step > 0 && t - (L+1)*step > 0)
+            // fails; both hold for every L below it, so the walk may start anywhere at or below
+            // L*.  With q = t / step, L* is ceil(q) - 1 up to the rounding of these fp32
+            // expressions when q is within ~1e-5 of an integer k (then k - 1 or k), and
+            // floor(t * (D - 1)) is floor(q) up to the same (k - 1 or k): one below it is
+            // never above L*, and is L* - 1 for all but those boundary cases -- one loop
+            // iteration instead of two (round 1 started two below).
+            L = max(0, (int)(t * (p.D - 1)) - 1);
             while ((t - (0.0f + L * step) > 0) && (t - (0.0f + (L + 1) * step) > 0)) L++;
         }
         int left = max(wave_scan_max(valid ? L : 0), carry);

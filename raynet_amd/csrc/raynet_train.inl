@@ -214,7 +214,7 @@ __global__ __launch_bounds__(BLOCK) void k_plane_weights(Params p, int n,
             vd -= s[2];
             sum += ray[2] * vd;
             t = clampf(sum / ray_norm, eps, 1 - eps);
-            L = max(0, (int)(t * (p.D - 1)) - 2);
+            L = max(0, (int)(t * (p.D - 1)) - 1);      // (see map_planes_to_voxels)
             while ((t - (0.0f + L * step) > 0) && (t - (0.0f + (L + 1) * step) > 0)) L++;
         }
         const int left = max(wave_scan_max(valid ? L : 0), carry);
