@@ -844,15 +844,13 @@ __global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S
     if (!depth_map) return;
     // raynet_fp.py:193-226.  Entries beyond count are zero in the reference's zero-filled
     // buffer and every d_i > 0, so the arg-max lies in [0, count); for count <= 1 the row is
-    // all zeros and index 0 wins.
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o);
-        const int oi = __shfl_xor(best_i, o);
-        if (ob > best || (ob == best && oi < best_i)) {
-            best = ob;
-            best_i = oi;
-        }
+    // all zeros and index 0 wins.  First maximum of the wave: the largest value (DPP
+    // reduction), then the smallest index among the lanes that hold it -- two reductions on
+    // the VALU instead of a six-step shuffle butterfly through LDS.
+    {
+        const float top = wave_max(best);
+        best_i = wave_min_i(best == top ? best_i : 0x7fffffff);
+        if (best_i == 0x7fffffff) best_i = 0;       // (a NaN column: nobody equals the maximum)
     }
     if (lane == 0) {
         const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
