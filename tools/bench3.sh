@@ -1,3 +1,4 @@
+# usage on the GPU box: bash tools/bench3.sh <label>   -- three bench.py runs, per-kernel ms per step
 cd $GRAFT_REPO_ROOT
 for i in 1 2 3; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
