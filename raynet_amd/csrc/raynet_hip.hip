@@ -14,6 +14,10 @@ using namespace rn;
 namespace {
 
 constexpr int BLOCK = 256;               // 4 wavefronts = 4 rays per workgroup
+// threads per workgroup of the wave-per-ray MRF kernels (k_bp, k_depth): A/B knob
+#ifndef RN_RAY_BLOCK
+#define RN_RAY_BLOCK 256
+#endif
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
 constexpr int NXCD = 8;
 
@@ -32,7 +36,7 @@ __device__ __forceinline__ int ray_of_wave(int n, int &lane) {
     const int b = xcd_block(blockIdx.x, gridDim.x);
     // the wave's ray index lives in an SGPR (the compiler cannot see that threadIdx.x >> 6 is
     // wave-uniform): row addresses become scalar base + per-lane 32-bit offset
-    const int r = uniform(b * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    const int r = uniform(b * (int)(blockDim.x >> 6) + (threadIdx.x >> 6));
     return r < n ? r : -1;
 }
 
@@ -114,18 +118,19 @@ struct rn_ctx {
     bool box_pin;         // RAYNET_HIP_BOX_PIN: stay at the starting level (A/B runs)
     unsigned *box_stats, *box_stats_host;
     hipEvent_t ev0, ev1;
-    // second stream of the resident-scene launchers (RAYNET_HIP_OVERLAP=1, default off): the
-    // accumulator scatter of one half of a launch's rows runs next to the BP sweep of the
-    // other half, the traversal of half of the images next to the plane sweep of the rest.
-    // Measured (profiles/r02_exp_overlap.txt): config 2 8.72 -> 8.84 ms/step (either kernel
-    // alone already keeps the VALUs of every CU busy), config 4 44.3 -> 42.5 (its scatter
-    // waits on L2 atomics: 3.9 hits per voxel)
+    // second stream of the resident-scene launchers (RAYNET_HIP_OVERLAP=0 / 1, default: by
+    // the scatter's tile level): the accumulator scatter of one half of a launch's rows runs
+    // next to the BP sweep of the other half, the traversal of half of the images next to the
+    // plane sweep of the rest.  Measured (profiles/r02_exp_overlap.txt): config 2 8.72 ->
+    // 8.84 ms/step (either kernel alone already keeps the VALUs of every CU busy), config 4
+    // 44.3 -> 42.5 (its scatter waits on L2 atomics at 3.9 hits per voxel) -- and config 4 is
+    // where the adaptive scatter has stepped to its second tile shape, so that is the switch
     // slab boxes (rn_scene_bind_slab_boxes): table, the list buffer it describes, and the row
     // range rn_scene_prepare_all last filled
     const int32_t *sb_vox;
     int64_t sb_rows, sb_valid_lo, sb_valid_hi;
     int2 *sb_boxes;
-    bool overlap;
+    int overlap;          // 0 off, 1 on, 2 (default) when the scatter runs at tile level >= 1
     hipStream_t aux;
     hipEvent_t ev_fork, ev_join;
     // per-launch profiling (rn_prof_begin / rn_prof_end)
@@ -182,6 +187,7 @@ int fail(rn_ctx *ctx, int code, const char *fmt, ...) {
 
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ray_blocks(int n) { return (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; }
+inline int ray_blocks_mrf(int n) { return (n + RN_RAY_BLOCK / WAVE - 1) / (RN_RAY_BLOCK / WAVE); }
 inline int thread_blocks(int n) { return (n + BLOCK - 1) / BLOCK; }
 inline int fill_blocks(int64_t n) {
     int64_t b = (n + BLOCK - 1) / BLOCK;
@@ -272,7 +278,7 @@ void launch_bp_kernel(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, c
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     ProfScope prof(ctx, RN_K_BP, n, st);
 #define RN_BP(NCH_)                                                                            \
-    hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
+    hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks_mrf(n)), dim3(RN_RAY_BLOCK), 0, st, \
                        ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, msgs_out, uniform_acc ? 1 : 0)
     if (nch <= 2) RN_BP(2);
     else if (nch <= 4) RN_BP(4);
@@ -344,7 +350,8 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     // by LDS atomics and barriers: with the rows in two halves the scatter of the first half
     // runs (on the context's second stream) while the second half's messages are computed.
     const size_t M = (size_t)ctx->p.M, VW = PACKED ? 1 : 3;
-    const int nA = ctx->overlap && PACKED && n >= 65536 ? (n / 2 + 255) / 256 * 256 : n;
+    const bool split = ctx->overlap == 1 || (ctx->overlap == 2 && level >= 1 && level < LAST);
+    const int nA = split && PACKED && n >= 65536 ? (n / 2 + 255) / 256 * 256 : n;
     launch_bp_kernel<PACKED, CLIP_IN>(ctx, nA, Sv, vox, rvc, acc_in, msgs_in, msgs_out, st, uniform_acc);
     RN_LAUNCH_CHECK(ctx);
     if (nA < n) {
@@ -381,7 +388,7 @@ int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const 
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     ProfScope prof(ctx, RN_K_DEPTH, n, st);
 #define RN_DE(NCH_)                                                                             \
-    hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks(n)), dim3(BLOCK), 0, st, \
+    hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks_mrf(n)), dim3(RN_RAY_BLOCK), 0, st, \
                        ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, S_new, depth_map,           \
                        rays_per_center)
     if (nch <= 2) RN_DE(2);
@@ -450,7 +457,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     ctx->box_level = ctx->box_level0 = bs ? max(0, min(2, atoi(bs))) : 0;
     ctx->box_pin = getenv("RAYNET_HIP_BOX_PIN") != nullptr;
     const char *ov = getenv("RAYNET_HIP_OVERLAP");
-    ctx->overlap = ov && atoi(ov) != 0;
+    ctx->overlap = ov ? (atoi(ov) != 0 ? 1 : 0) : 2;
     if (sweep_lds(p) > 160 * 1024) {      // before anything is allocated
         delete ctx;
         return RN_ERR_INVALID;
@@ -859,7 +866,8 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
         a.seg = ray_segments ? ray_segments + row0 * 8 : nullptr;
         launch_sweep<2, true>(ctx, a, true, st);
     };
-    const int gA = ctx->overlap && n_images >= 2 && (int64_t)n * n_images >= 65536
+    const bool split = ctx->overlap == 1 || (ctx->overlap == 2 && ctx->box_level == 1);
+    const int gA = split && n_images >= 2 && (int64_t)n * n_images >= 65536
                        ? (n_images + 1) / 2 : n_images;
     if (gA < n_images) {
         // the thread-per-ray traversal (a chain of dependent fp32 additions per ray, few waves

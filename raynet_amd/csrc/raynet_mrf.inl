@@ -209,7 +209,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
 }
 
 template <int NCH, bool PACKED, bool CLIP_IN>
-__global__ __launch_bounds__(BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
+__global__ __launch_bounds__(RN_RAY_BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
                                               const int32_t *__restrict__ vox,
                                               const int32_t *__restrict__ rvc,
                                               const float *__restrict__ acc_in,
@@ -816,7 +816,7 @@ __device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int
 }
 
 template <int NCH, bool PACKED, bool CLIP_IN>
-__global__ __launch_bounds__(BLOCK) void k_depth(Params p, int n, const float *S,
+__global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const float *S,
                                                  const int32_t *__restrict__ vox,
                                                  const int32_t *__restrict__ rvc,
                                                  const float *__restrict__ acc,
