@@ -554,7 +554,8 @@ class RayNetForwardPass(ForwardPass):
                                 rvc=plan["rvc"][row0:row0 + n], msgs=plan["msgs"][row0:row0 + n],
                                 depth=plan["depth"][row0:row0 + n])
         plan["per_image"] = per_image
-        if hasattr(ctx, "bind_slab_boxes") and os.environ.get("RAYNET_SLAB_BOXES", "1") != "0":
+        if hasattr(ctx, "bind_slab_boxes") and plan["vox"].numel() >= M and \
+                os.environ.get("RAYNET_SLAB_BOXES", "1") != "0":
             ctx.bind_slab_boxes(plan["vox"])      # the scatters merge boxes the traversal left
         if not self._filter_out_rays:
             self._plan = plan
