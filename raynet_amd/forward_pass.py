@@ -566,6 +566,8 @@ class RayNetForwardPass(ForwardPass):
         gp = self._generation_params
         H, W = scene.image_shape
         refs = list(range(start, end, skip))
+        if not refs:            # an empty image range yields nothing (forward_pass.py:597-602)
+            return
         dist, rank, world = _dist()
         # an initialised process group runs its collectives even when it has ONE rank (that is
         # how a single-GPU box exercises the RCCL path); no group, no collectives
@@ -794,6 +796,8 @@ class RayNetForwardPass(ForwardPass):
         M = gp.max_number_of_marched_voxels
         H, W = scene.image_shape
         refs = list(range(start, end, skip))
+        if not refs:
+            return
         prior = self._prior()
         msgs_all = {}
         ctx = None

@@ -743,3 +743,26 @@ def test_slab_boxes_and_second_stream_change_nothing(torch, monkeypatch):
     assert ref[2] in (0, 1)             # the LDS-box scatter is what ran
     for key, (d, acc, _) in runs.items():
         assert np.array_equal(acc, ref[1]) and np.array_equal(d, ref[0]), key
+
+
+def test_edge_ranges_and_zero_iterations(torch, oracle_mod):
+    """Empty image range, a single image, a strided range, and bp_iterations = 0 (the depth
+    sweep then runs on the prior and zero messages: the arg-max of o T s with a constant o)."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W, D, M, grid = 24, 32, 16, 96, (32, 32, 32)
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(D, M, grid)
+    cls = get_forward_pass_factory("raynet")
+    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0)
+    assert list(fp.forward_pass(scene, (2, 2, 1))) == []
+    one = list(fp.forward_pass(scene, (3, 4, 1)))
+    assert len(one) == 1 and one[0].shape == (H, W) and np.isfinite(one[0]).all()
+    strided = list(fp.forward_pass(scene, (0, 5, 2)))
+    assert len(strided) == 3 and all(d.shape == (H, W) for d in strided)
+    fp0 = cls(bank, gp, "sample_in_bbox", (H, W), 0, bp_iterations=0)
+    d0 = list(fp0.forward_pass(scene, (0, 2, 1)))
+    acc, msgs, depths, _ = _oracle_forward(oracle_mod, scene, bank, gp, [0, 1], H, W, iters=0)
+    assert np.allclose(fp0.accumulator.cpu().numpy(), acc)         # the prior everywhere
+    for r in (0, 1):
+        assert (np.abs(d0[r] - depths[r]) > 1e-4).mean() < 0.01
