@@ -85,23 +85,28 @@ def test_resident_vs_reference_schedule_vs_oracle(torch, oracle_mod, quirks):
              reference_quirks=quirks)
     db = list(fb.forward_pass(scene, refs))
     assert len(da) == len(db) == 3 and da[0].shape == (H, W) and da[0].dtype == np.float32
-    acc_o, msgs_o, depth_o, dist_o = _oracle_forward(oracle_mod, scene, bank, gp, [0, 1, 2], H, W,
-                                                     quirks=quirks)
+    # the comparator is the oracle's robust message form (pinned to the reference's NumPy path,
+    # tests/test_saturated_golden.py): on this planted scene messages reach |m| = 12, where the
+    # literal fp32 (cumsum1 - cumsum2) of mrf_bp.cu:157 is itself wrong by 1e-2
+    oracle_mod.Oracle.set_robust_messages(True)
+    try:
+        acc_o, msgs_o, depth_o, dist_o = _oracle_forward(oracle_mod, scene, bank, gp, [0, 1, 2],
+                                                         H, W, quirks=quirks)
+    finally:
+        oracle_mod.Oracle.set_robust_messages(False)
     acc_a, acc_b = fa.accumulator.cpu().numpy(), fb.accumulator.cpu().numpy()
-    assert np.abs(acc_a - acc_b).max() < 2e-3
-    assert np.abs(acc_a - acc_o).max() < 5e-3
+    assert np.abs(acc_a - acc_b).max() <= 2e-4
+    assert np.abs(acc_a - acc_o).max() <= 2e-4
     for i, r in enumerate([0, 1, 2]):
         assert _depth_close(da[i], depth_o[i], dist_o[i], W, H) <= 0.01
         assert _depth_close(db[i], depth_o[i], dist_o[i], W, H) <= 0.01
         rows = fa.messages[r].cpu().numpy()        # row i belongs to ray fa.ray_index[r][i]
         m = np.zeros_like(rows)
         m[fa.ray_index[r].cpu().numpy().astype(np.int64)] = rows
-        # three coupled iterations: every message inherits the (float-atomic ordered)
-        # accumulator's rounding, amplified by the logit conditioning exp(|m|)
-        tol = 2e-3 + 512 * 2.0 ** -24 * np.exp(np.minimum(np.abs(msgs_o[r]), 17.0))
         err = np.abs(m - msgs_o[r])
-        assert np.all(err <= tol), "worst %g at |m|=%g (ratio %g)" % (
-            err.max(), np.abs(msgs_o[r]).ravel()[err.argmax()], (err / tol).max())
+        assert err.max() <= 1e-4, "worst %g at |m|=%g" % (
+            err.max(), np.abs(msgs_o[r]).ravel()[err.argmax()])
+        assert np.abs(fb.messages[r].cpu().numpy() - msgs_o[r]).max() <= 1e-4
 
 
 def test_mvcnn_twin_as_model_and_other_drivers(torch, oracle_mod):
