@@ -307,7 +307,7 @@ def test_sharded_ranks_on_real_kernels(torch, tmp_path, world):
     for rq in ranks[1:]:
         assert np.array_equal(r0["acc"], rq["acc"]) and np.array_equal(r0["depth"], rq["depth"])
         assert np.array_equal(r0["balance"], rq["balance"])
-    assert np.abs(one["acc"] - r0["acc"]).max() < 5e-3
+    assert np.abs(one["acc"] - r0["acc"]).max() < 5e-4
     assert (np.abs(one["depth"] - r0["depth"]) > 1e-4).mean() < 0.01
     # every ray owned once; what the cuts equalise is a rank's WEIGHT -- its traversed voxels
     # plus 0.6 x the mean count for every ray (the plane sweep costs the same for every ray) --
@@ -414,6 +414,17 @@ def test_row_layout_does_not_change_results(torch, filter_rays, monkeypatch):
         masks = {i: (rng.random((H, W)) > 0.3).astype(np.float32) for i in range(5)}
         monkeypatch.setattr(type(scene), "get_depth_map", lambda self, i: masks[i], raising=False)
     cls = get_forward_pass_factory("raynet")
+    # fixed-point sums: the row layout (and with it the scatter kernel and its summation order)
+    # must not change a single bit
+    det = {}
+    for tile in ((16, 16), None, (8, 32)):
+        fp = cls(bank, _gp(D, M, grid), "sample_in_bbox", (H, W), 0, filter_out_rays=filter_rays,
+                 deterministic=True)
+        fp.ray_tile = tile
+        d = np.stack(list(fp.forward_pass(scene, (0, 3, 1))))
+        det[tile] = (d, fp.accumulator.cpu().numpy())
+    for tile in ((16, 16), (8, 32)):
+        assert np.array_equal(det[tile][1], det[None][1]) and np.array_equal(det[tile][0], det[None][0])
     res = {}
     for tile in ((16, 16), None, (8, 32)):
         fp = cls(bank, _gp(D, M, grid), "sample_in_bbox", (H, W), 0, filter_out_rays=filter_rays)
@@ -428,10 +439,9 @@ def test_row_layout_does_not_change_results(torch, filter_rays, monkeypatch):
         assert (ref[0][0][masks[0] == 0] == 0).all() and (ref[0][0][masks[0] != 0] > 0).any()
     for tile in ((16, 16), (8, 32)):
         d, acc, m = res[tile]
-        assert np.abs(acc - ref[1]).max() < 2e-3
+        assert np.abs(acc - ref[1]).max() <= 2e-4         # float atomics: the order of the sums
         assert (np.abs(d - ref[0]) > 1e-4).mean() < 0.01
-        tol = 2e-3 + 512 * 2.0 ** -24 * np.exp(np.minimum(np.abs(ref[2]), 17.0))
-        assert np.all(np.abs(m - ref[2]) <= tol)
+        assert np.abs(m - ref[2]).max() <= 1e-4
 
 
 def test_deterministic_mode_is_bit_identical_across_runs_and_ranks(torch, tmp_path):
