@@ -231,16 +231,20 @@ def test_config1_restrepo_cameras(torch, oracle_mod):
                    np.array([scene.get_image(v).camera.P for v in views], np.float32),
                    scene.get_image(r).camera.P_pinv.astype(np.float32),
                    scene.get_image(r).camera.center.ravel().astype(np.float32))
-    acc = o.prior(0.05)
-    msgs = {r: np.zeros((H * W, 96), np.float32) for r in range(3)}
-    for it in range(3):
-        out = o.prior(0.05)
-        for r in range(3):
-            f, P, Pi, c = cams[r]
-            rvi, rvc, _ = o.fused_bp(ridx, f, P, Pi, c, vg, acc, msgs[r], out)
-        acc = out
+    oracle_mod.Oracle.set_robust_messages(True)      # (see test_resident_vs_reference_schedule_vs_oracle)
+    try:
+        acc = o.prior(0.05)
+        msgs = {r: np.zeros((H * W, 96), np.float32) for r in range(3)}
+        for it in range(3):
+            out = o.prior(0.05)
+            for r in range(3):
+                f, P, Pi, c = cams[r]
+                rvi, rvc, _ = o.fused_bp(ridx, f, P, Pi, c, vg, acc, msgs[r], out)
+            acc = out
+    finally:
+        oracle_mod.Oracle.set_robust_messages(False)
     assert rvc.max() > 10      # the aerial cameras do see the box
-    assert np.abs(fp.accumulator.cpu().numpy() - acc).max() < 5e-3
+    assert np.abs(fp.accumulator.cpu().numpy() - acc).max() <= 2e-4
     for r in range(3):
         f, P, Pi, c = cams[r]
         _, _, S_new, depth = o.fused_depth(ridx, f, P, Pi, c, vg, acc, msgs[r])
@@ -367,7 +371,7 @@ def test_rccl_code_path_in_a_one_rank_world(torch, tmp_path):
         assert q.exitcode == 0
     got = np.load(out + "/nccl.npz")
     ref, ref_d = np.load(out + "/w1_r0.npz"), np.load(out + "/dw1_r0.npz")
-    assert np.abs(got["acc"] - ref["acc"]).max() < 5e-3
+    assert np.abs(got["acc"] - ref["acc"]).max() < 5e-4
     assert (np.abs(got["depth"] - ref["depth"]) > 1e-4).mean() < 0.01
     assert np.array_equal(got["acc_fixed"], ref_d["acc"])          # fixed point: the same bits
     assert np.array_equal(got["depth_fixed"], ref_d["depth"])
@@ -480,7 +484,7 @@ def test_deterministic_mode_is_bit_identical_across_runs_and_ranks(torch, tmp_pa
     p.join(300)
     assert p.exitcode == 0
     ref = np.load(out + "/w1_r0.npz")
-    assert np.abs(ref["acc"] - runs[0][0]).max() < 2e-3
+    assert np.abs(ref["acc"] - runs[0][0]).max() < 5e-4
     assert (np.abs(ref["depth"] - runs[0][1]) > 1e-4).mean() < 0.01
 
 
