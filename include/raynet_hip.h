@@ -313,6 +313,12 @@ int rn_prof_offsets(rn_ctx *ctx, float *start_ms_host);
 /* Self-test of the exact arithmetic shortcut of the index maps (raynet_kernels.h:
  * round_half_away), for tests/: out is [2][n] -- roundf(a), round_half_away(a). */
 int rn_selftest_arith(rn_ctx *ctx, int32_t n, const float *a, float *out, void *stream);
+/* The same for round_quotient_fast, which stands in for the two divisions of a projection
+ * (feature_similarities.cu:24-25) wherever it is sure of the rounded result: out is [3][n] --
+ * round_half_away(x / d), the shortcut's value, 1.0 where it is sure (elsewhere the kernels
+ * take the division). */
+int rn_selftest_quotient(rn_ctx *ctx, int32_t n, const float *x, const float *d, float *out,
+                         void *stream);
 
 /* ---- differentiable MRF block (training) --------------
  * The reference builds this block from TensorFlow ops and lets autodiff

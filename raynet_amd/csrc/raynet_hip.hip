@@ -81,6 +81,21 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_arith(int n, const float *__
     out[i] = roundf(a[i]);
     out[(size_t)n + i] = round_half_away(a[i]);
 }
+// round_quotient_fast next to the division it replaces (rn_selftest_quotient); per LANE here,
+// where the sweep falls back per wavefront
+__global__ __launch_bounds__(BLOCK) void k_selftest_quotient(int n, const float *__restrict__ x,
+                                                             const float *__restrict__ d,
+                                                             float *out) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    bool sure;
+    const float rd = __builtin_amdgcn_rcpf(d[i]);
+    const float fast = round_quotient_fast(x[i], rd, sure);
+    sure = sure && reciprocal_is_normal(rd);
+    out[i] = round_half_away(x[i] / d[i]);
+    out[(size_t)n + i] = fast;
+    out[2 * (size_t)n + i] = sure ? 1.0f : 0.0f;
+}
 // resident (bricked) accumulator <-> the reference's [gx][gy][gz] array
 template <bool TO_GRID>
 __global__ void k_acc_regrid(Params p, const float *__restrict__ src, float *dst) {
@@ -1031,6 +1046,16 @@ int rn_selftest_arith(rn_ctx *ctx, int32_t n, const float *a, float *out, void *
     if (ctx && n == 0) return RN_OK;
     if (!ctx || n < 0 || !a || !out) return fail(ctx, RN_ERR_INVALID, "bad argument");
     hipLaunchKernelGGL(k_selftest_arith, dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream), n, a, out);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_selftest_quotient(rn_ctx *ctx, int32_t n, const float *x, const float *d, float *out,
+                         void *stream) {
+    if (ctx && n == 0) return RN_OK;
+    if (!ctx || n < 0 || !x || !d || !out) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_selftest_quotient, dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream), n, x,
+                       d, out);
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }

@@ -145,6 +145,25 @@ __device__ __forceinline__ float round_half_away(float x) {
     return __builtin_truncf(x + __builtin_copysignf(0x1.fffffep-2f, x));
 }
 
+// round_half_away(x / n) without the division, for the pixel a projection lands on.  Only the
+// rounded quotient is used, never the quotient: q' = x * rcp(n) is within 2^-22 |q| of the
+// correctly rounded x / n (v_rcp_f32: 1 ulp = 2^-23 relative; the product: 2^-24; RN(x / n)
+// itself: 2^-24), so the two round to the same integer unless q' lies within that distance of
+// a rounding boundary k + 1/2.  |q' - round(q')| <= 1/2 always; `sure` = it stays 2^-21 |q'|
+// short of 1/2 (false for a non-finite q' and for |q'| >= 2^20).  The bound on rcp needs a
+// NORMAL reciprocal (a divisor beyond 2^126 has a denormal one, flushed to zero; a denormal
+// divisor an infinite one): reciprocal_is_normal, one v_cmp_class per divisor.  The caller
+// takes the IEEE division when it is not sure; rn_selftest_quotient puts the two side by side.
+__device__ __forceinline__ bool reciprocal_is_normal(float rcp_n) {
+    return __builtin_amdgcn_class(rcp_n, 0x108);     // -normal | +normal
+}
+__device__ __forceinline__ float round_quotient_fast(float x, float rcp_n, bool &sure) {
+    const float q = x * rcp_n;
+    const float r = round_half_away(q);
+    sure = __builtin_fabsf(q - r) < __builtin_fmaf(__builtin_fabsf(q), -0x1p-21f, 0.5f);
+    return r;
+}
+
 // ------------------------------------------------------------------- a1
 // sampling_schemes.cu:44-90; arithmetic identical to oracle rno_sample_in_bbox
 __device__ __forceinline__ void sample_in_bbox(const Params &p, int ray_idx,
@@ -207,7 +226,9 @@ __device__ __forceinline__ int feature_offset(const Params &p, const float *__re
 // BYTE offset and with fewer instructions, every step exact: the 3-instruction round,
 // `+ padding - half` as one addition (exact on integer-valued floats; beyond 2^24 the clamp
 // decides either way), the clamp as one v_med3_f32 before the conversion (NaN -> 0 like the
-// saturating v_cvt_i32_f32), a 24-bit multiply and a shift instead of two 32-bit multiplies.
+// saturating v_cvt_i32_f32), a 24-bit multiply and a shift instead of two 32-bit multiplies,
+// and the two IEEE divisions only for the wavefronts in which some lane's quotient is too close
+// to a rounding boundary for round_quotient_fast (-DRN_IEEE_QUOTIENTS: always).
 template <int LOG2_VEC_BYTES>
 __device__ __forceinline__ int feature_offset_bytes(const Params &p,
                                                     const float *__restrict__ Pv,
@@ -216,8 +237,21 @@ __device__ __forceinline__ int feature_offset_bytes(const Params &p,
     x += Pv[0] * point[0]; x += Pv[1] * point[1]; x += Pv[2] * point[2]; x += Pv[3] * 1;
     y += Pv[4] * point[0]; y += Pv[5] * point[1]; y += Pv[6] * point[2]; y += Pv[7] * 1;
     n += Pv[8] * point[0]; n += Pv[9] * point[1]; n += Pv[10] * point[2]; n += Pv[11] * 1;
+#ifndef RN_IEEE_QUOTIENTS
+    const float rn = __builtin_amdgcn_rcpf(n);
+    bool sure_x, sure_y;
+    float rx = round_quotient_fast(x, rn, sure_x), ry = round_quotient_fast(y, rn, sure_y);
+    if ((__builtin_amdgcn_ballot_w64(sure_x) & __builtin_amdgcn_ballot_w64(sure_y) &
+         __builtin_amdgcn_ballot_w64(reciprocal_is_normal(rn))) != __builtin_amdgcn_read_exec()) {         // ~4 % of the wavefronts per view at config 2
+        rx = round_half_away(x / n);
+        ry = round_half_away(y / n);
+    }
+    rx += pad_shift;
+    ry += pad_shift;
+#else
     const float rx = round_half_away(x / n) + pad_shift;
     const float ry = round_half_away(y / n) + pad_shift;
+#endif
     const unsigned fx = (unsigned)(int)__builtin_amdgcn_fmed3f(rx, 0.0f, (float)p.W);
     const unsigned fy = (unsigned)(int)__builtin_amdgcn_fmed3f(ry, 0.0f, (float)p.H);
     const unsigned off = (__umul24(fy, (unsigned)p.Wf) + fx) << LOG2_VEC_BYTES;

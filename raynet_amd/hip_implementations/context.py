@@ -265,6 +265,11 @@ class HipContext(object):
         """out[2][n]: roundf(a), round_half_away(a) (tests only)."""
         self._check(self.lib.rn_selftest_arith(self._h, a.numel(), _ptr(a), _ptr(out), _stream()))
 
+    def selftest_quotient(self, x, d, out):
+        """out[3][n]: round_half_away(x / d), round_quotient_fast's value, sure (tests only)."""
+        self._check(self.lib.rn_selftest_quotient(self._h, x.numel(), _ptr(x), _ptr(d), _ptr(out),
+                                                  _stream()))
+
     # -- thin wrappers; argument order is the header's ------------------------
     def fill_f32(self, t, value):
         self._check(self.lib.rn_fill_f32(self._h, _ptr(t), t.numel(), float(value), _stream()))

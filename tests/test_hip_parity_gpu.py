@@ -887,3 +887,51 @@ def test_exact_arithmetic_shortcuts(torch, oracle_mod):
         expect = np.where(np.isfinite(a), np.trunc(a.astype(np.float64) + np.copysign(0.5, a)), a)
     fin = np.isfinite(a)
     assert np.array_equal(out[0][fin], expect.astype(np.float32)[fin])
+
+
+def test_rounded_quotient_shortcut(torch, oracle_mod):
+    """round_quotient_fast (x * rcp(d), rounded) == roundf(x / d) bit for bit wherever it says
+    it is sure: quotients planted within a few ulps of every rounding boundary k + 1/2 of a
+    feature map's extent (where it must NOT be sure when the two could differ), ordinary
+    projections, and random bit patterns (infinities, NaNs, denormals, zero divisors)."""
+    o, _, _ = make_case(oracle_mod, CU["small"])
+    ctx = hip_ctx(o)
+    rng = np.random.default_rng(11)
+    n = 1 << 22
+    x = np.empty(n, np.float32)
+    d = np.empty(n, np.float32)
+    q = n // 4
+    # (a) next to the boundaries: x = RN((k + 1/2) * d) moved by -3 .. 3 ulps
+    dd = (rng.uniform(0.05, 40.0, q) * rng.choice([-1.0, 1.0], q)).astype(np.float32)
+    k = rng.integers(-64, 4096, q).astype(np.float32)
+    xx = ((k + np.float32(0.5)) * dd).astype(np.float32)
+    xx = (xx.view(np.int32) + rng.integers(-3, 4, q).astype(np.int32)).view(np.float32)
+    x[:q], d[:q] = xx, dd
+    # (b) the same with exactly representable half-way quotients (d a power of two)
+    dd = (np.float32(2.0) ** rng.integers(-6, 6, q).astype(np.float32)).astype(np.float32)
+    x[q:2 * q], d[q:2 * q] = ((k + np.float32(0.5)) * dd).astype(np.float32), dd
+    # (c) ordinary projections: pixel coordinates anywhere near an image, depths 0.1 .. 30
+    dd = rng.uniform(0.1, 30.0, q).astype(np.float32)
+    x[2 * q:3 * q], d[2 * q:3 * q] = (rng.uniform(-300.0, 2500.0, q) * dd).astype(np.float32), dd
+    # (d) anything
+    x[3 * q:] = rng.integers(0, 1 << 32, q, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    d[3 * q:] = rng.integers(0, 1 << 32, q, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    out = torch.zeros((3, n), device="cuda")
+    ctx.selftest_quotient(torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(), out)
+    exact, fast, sure = out.cpu().numpy()
+    sure = sure > 0
+    same = exact.view(np.uint32) == fast.view(np.uint32)
+    bad = np.flatnonzero(sure & ~same)
+    assert bad.size == 0, ("round_quotient_fast is sure of a value the division does not give",
+                           x[bad[:8]], d[bad[:8]], exact[bad[:8]], fast[bad[:8]])
+    # the division agrees with the host's, so `exact` is the reference's arithmetic
+    with np.errstate(all="ignore"):
+        host = x / d
+        fin = np.isfinite(host) & (np.abs(host) < 2.0 ** 22)
+        expect = np.trunc(host.astype(np.float64) + np.copysign(0.5, host))
+    assert np.array_equal(exact[fin], expect[fin].astype(np.float32))
+    # it is sure of nearly all ordinary projections (the fallback stays rare) and of nothing
+    # that is not finite
+    assert sure[2 * q:3 * q].mean() > 0.995
+    assert not sure[~np.isfinite(fast)].any()
+    assert not sure[q:2 * q].any()          # exact half-way cases are never "sure"
