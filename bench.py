@@ -19,6 +19,9 @@ Prints ONE JSON line on rank 0.  Extra objects:
   roofline     dominant kernel family: algorithmic bytes of its
                launches in the timed region / their hipEvent durations (per launch, on
                the launch stream, via rn_prof_begin/rn_prof_end), vs the 8 TB/s HBM peak
+  kernels      every family's share of a step, from up to 3 untimed steps before the timed
+               region with every launch bracketed (the timed region brackets the dominant
+               family's launches only, unless --events all)
   cpu_baseline two legs on bounded ray samples of the same scene (rays of all reference
                images), on this box's host cores: "port" = the C oracle's fused K1/K2 path
                (the reference's algorithm, OpenMP over rays, all cores) -- also the object's
@@ -88,6 +91,9 @@ def main():
     ap.add_argument("--schedule", default="resident", choices=["resident", "reference"])
     ap.add_argument("--rays-batch", type=int, default=0, help="0 = one launch per image shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--events", default="dominant", choices=["dominant", "all"],
+                    help="launches bracketed by HIP events inside the timed region: those of the "
+                         "dominant kernel family (the roofline block), or all of them")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -143,8 +149,23 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx = fp._ctx
+    # Per-kernel breakdown: untimed steps with every launch bracketed by an event pair.  The
+    # timed region then brackets the launches of the dominant family only (--events all: every
+    # launch, as the breakdown steps do): an event pair costs the stream a few microseconds,
+    # ~20 of them per step are 1 % of a one-GPU step and 5 % of an eight-GPU one.
     fence()
-    ctx.prof_begin(capacity=64 * V * max(args.steps, 1) + 64)
+    breakdown_steps = max(1, min(3, args.steps))
+    ctx.prof_begin(capacity=64 * V * breakdown_steps + 64)
+    for _ in range(breakdown_steps):
+        step()
+    fence()
+    launches_all = ctx.prof_end()
+    by_family = {}
+    for name, _, ms in launches_all:
+        by_family[name] = by_family.get(name, 0.0) + ms
+    dominant = max((k for k in by_family if k != "acc"), key=lambda k: by_family[k], default=None)
+    only = [dominant] if (args.events == "dominant" and dominant) else None
+    ctx.prof_begin(capacity=64 * V * max(args.steps, 1) + 64, only=only)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -166,23 +187,28 @@ def main():
         vox_by_n.setdefault(int(c.numel()), []).append(float(c.sum().item()))
     mean_vox = float(sum(float(c.sum().item()) for c in counts.values()) /
                      max(1, sum(int(c.numel()) for c in counts.values())))
-    fam = {}
     cfg_acc = dict(cfg, views=gp.neighbors + 1)
-    for name, n_rays, ms in launches:
-        f = fam.setdefault(name, dict(ms=0.0, launches=0, bytes=0.0))
-        f["ms"] += ms
-        f["launches"] += 1
-        if n_rays:
-            # launches are per image shard: voxels of a launch = mean over images with n rays
-            vs = vox_by_n.get(n_rays)
-            vox = float(np.mean(vs)) if vs else mean_vox * n_rays
-            per_image = max(1, min(int(c.numel()) for c in counts.values())) if counts else n_rays
-            f["bytes"] += algorithmic_bytes(name, n_rays, vox, cfg_acc,
-                                            images=max(1, n_rays // per_image))
-    dominant = max((k for k in fam if k != "acc"), key=lambda k: fam[k]["ms"], default=None)
+
+    def account(recorded):
+        fam = {}
+        for name, n_rays, ms in recorded:
+            f = fam.setdefault(name, dict(ms=0.0, launches=0, bytes=0.0))
+            f["ms"] += ms
+            f["launches"] += 1
+            if n_rays:
+                # launches are per image shard: voxels of a launch = mean over images with n rays
+                vs = vox_by_n.get(n_rays)
+                vox = float(np.mean(vs)) if vs else mean_vox * n_rays
+                per_image = max(1, min(int(c.numel()) for c in counts.values())) if counts else n_rays
+                f["bytes"] += algorithmic_bytes(name, n_rays, vox, cfg_acc,
+                                                images=max(1, n_rays // per_image))
+        return fam
+
+    fam = account(launches_all)             # the breakdown steps: every family
+    timed = account(launches)               # the timed region: the dominant family (or all)
     roofline = None
-    if dominant:
-        d = fam[dominant]
+    if dominant and dominant in timed:
+        d = timed[dominant]
         achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
         # HBM-side bytes per launch come from PMC counters, which need their own rocprofv3
         # passes (tools/pmc_passes.sh): the figure is read from the summary committed for
@@ -203,8 +229,8 @@ def main():
                         traffic=traffic, traffic_source=traffic_source,
                         avg_launch_ms=round(d["ms"] / d["launches"], 4), launches=d["launches"],
                         algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]))
-    kernels = {k: dict(total_ms_per_step=round(v["ms"] / args.steps, 3),
-                       launches_per_step=v["launches"] / args.steps,
+    kernels = {k: dict(total_ms_per_step=round(v["ms"] / breakdown_steps, 3),
+                       launches_per_step=v["launches"] / breakdown_steps,
                        algorithmic_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
                        if v["ms"] > 0 and v["bytes"] else None)
                for k, v in sorted(fam.items())}
@@ -328,6 +354,9 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": kernels,
+            "kernel_events": {"breakdown_steps_untimed": breakdown_steps,
+                              "timed_region": "all launches" if only is None else
+                              "launches of %s only" % dominant},
         }
         print(json.dumps(result))
     if world > 1:

@@ -304,6 +304,10 @@ typedef enum {
     RN_K_SCATTER = 7     /* accumulator scatter of the BP messages (tile-transposed) */
 } rn_kernel_id;
 int rn_prof_begin(rn_ctx *ctx, int32_t capacity);
+/* Which families the next rn_prof_begin brackets: bit (1 << rn_kernel_id) each, default all.
+ * An event pair costs the stream a few microseconds; a timed region that wants one kernel's
+ * durations only (bench.py: the dominant one) selects that family. */
+int rn_prof_select(rn_ctx *ctx, uint32_t kernel_mask);
 int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *n_rays_host,
                 float *ms_host);
 /* after rn_prof_end: start of every recorded launch, in ms after the first one's start

@@ -101,6 +101,7 @@ SIGNATURES = {
     "rn_acc_add_prior": [_P, _P, _F, _P],
     "rn_scene_depth": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "rn_prof_begin": [_P, _I],
+    "rn_prof_select": [_P, ctypes.c_uint32],
     "rn_prof_end": [_P, ctypes.POINTER(_I), _P, _P, _P],
     "rn_plane_weights": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "rn_train_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P],

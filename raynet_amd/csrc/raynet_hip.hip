@@ -150,6 +150,7 @@ struct rn_ctx {
     hipEvent_t ev_fork, ev_join;
     // per-launch profiling (rn_prof_begin / rn_prof_end)
     bool prof_on;
+    uint32_t prof_mask;       // which rn_kernel_id families are bracketed (rn_prof_select)
     int prof_cap, prof_n;
     hipEvent_t *prof_ev;      // 2 * prof_cap
     int32_t *prof_id, *prof_rays;
@@ -162,7 +163,7 @@ struct ProfScope {
     hipStream_t st;
     int slot;
     ProfScope(rn_ctx *ctx, int id, int n_rays, hipStream_t s) : c(ctx), st(s), slot(-1) {
-        if (c->prof_on && c->prof_n < c->prof_cap) {
+        if (c->prof_on && ((c->prof_mask >> id) & 1u) && c->prof_n < c->prof_cap) {
             slot = c->prof_n++;
             c->prof_id[slot] = id;
             c->prof_rays[slot] = n_rays;
@@ -473,6 +474,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     ctx->box_pin = getenv("RAYNET_HIP_BOX_PIN") != nullptr;
     const char *ov = getenv("RAYNET_HIP_OVERLAP");
     ctx->overlap = ov ? (atoi(ov) != 0 ? 1 : 0) : 2;
+    ctx->prof_mask = ~0u;
     if (sweep_lds(p) > 160 * 1024) {      // before anything is allocated
         delete ctx;
         return RN_ERR_INVALID;
@@ -1022,6 +1024,12 @@ int rn_prof_begin(rn_ctx *ctx, int32_t capacity) {
     }
     ctx->prof_n = 0;
     ctx->prof_on = true;
+    return RN_OK;
+}
+
+int rn_prof_select(rn_ctx *ctx, uint32_t kernel_mask) {
+    if (!ctx) return RN_ERR_INVALID;
+    ctx->prof_mask = kernel_mask;
     return RN_OK;
 }
 

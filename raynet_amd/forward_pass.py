@@ -757,8 +757,10 @@ class RayNetForwardPass(ForwardPass):
             # map depends on the ray lists and the sharding only: built once), ONE copy to the
             # host.  Pixels without a ray (filtered out) read the zero behind the blocks.
             HW = H * W
-            flat = torch.empty((world * n_all + 1,), dtype=torch.float32, device=dev)
-            flat[-1] = 0.0
+            if plan["stitch"] is None:
+                # held by the plan: the gathers never write the zero behind the blocks
+                plan["gathered"] = torch.zeros((world * n_all + 1,), dtype=torch.float32, device=dev)
+            flat = plan["gathered"]
             dist.all_gather_into_tensor(flat[:-1], depth_all)
             if plan["stitch"] is None:
                 src = torch.full((V * HW,), world * n_all, dtype=torch.int64, device=dev)

@@ -243,7 +243,15 @@ class HipContext(object):
 
     KERNEL_NAMES = {1: "traverse", 2: "sweep_map", 3: "bp", 4: "depth", 5: "acc", 6: "other", 7: "scatter"}
 
-    def prof_begin(self, capacity=4096):
+    def prof_begin(self, capacity=4096, only=None):
+        """only: kernel family names to bracket (None = all of them)."""
+        mask = 0xFFFFFFFF
+        if only is not None:
+            ids = {v: k for k, v in self.KERNEL_NAMES.items()}
+            mask = 0
+            for name in only:
+                mask |= 1 << ids[name]
+        self._check(self.lib.rn_prof_select(self._h, mask))
         self._prof_cap = capacity
         self._check(self.lib.rn_prof_begin(self._h, capacity))
 

@@ -33,8 +33,12 @@ class FakeDist(object):
     def all_reduce(self, t, op=None):
         pass
 
-    def all_gather_into_tensor(self, out, inp):
+    def all_gather_into_tensor(self, out, inp, async_op=False):
         out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
+        if async_op:        # like RCCL's work handle: wait() makes the CURRENT stream wait
+            ev = torch.cuda.Event()
+            ev.record()
+            return types.SimpleNamespace(wait=lambda: torch.cuda.current_stream().wait_event(ev))
 
 
 res = {}
@@ -50,7 +54,8 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
             step()
         ctx = fp._ctx
         torch.cuda.synchronize()
-        ctx.prof_begin(capacity=1024)
+        if not os.environ.get("NO_PROF"):      # what the per-launch event pairs themselves cost
+            ctx.prof_begin(capacity=1024)
         t0 = time.perf_counter()
         n = 20
         per_step = []
@@ -64,7 +69,7 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
             print("   (step times ms: median %.3f max %.3f at step %d)" % (
                 float(np.median(per_step)), max(per_step), int(np.argmax(per_step))))
         fam = {}
-        launches = ctx.prof_end()
+        launches = ctx.prof_end() if not os.environ.get("NO_PROF") else []
         for name, _, k_ms in launches:
             fam[name] = fam.get(name, 0.0) + k_ms / n
         if os.environ.get("TIMELINE") == "%d" % world and rank == 0:
