@@ -31,12 +31,24 @@ __device__ __forceinline__ int xcd_block(int b, int nblocks) {
     return start + pos;
 }
 
+// Every wave-per-ray kernel is launched as BS threads x ceil(n / (BS / 64)) workgroups, so the
+// grid and workgroup sizes follow from the kernel's own argument n: reading gridDim / blockDim
+// instead costs a wavefront that lives for ONE ray two more dependent fetches (the hidden
+// kernel arguments; blockDim even through the vector memory path) before its first row load:
+// k_depth -4 %, k_bp and k_sweep_map -1 % (profiles/r02_exp_wave_startup.txt).
+template <int BS = BLOCK>
 __device__ __forceinline__ int ray_of_wave(int n, int &lane) {
+    constexpr int WPB = BS / WAVE;
     lane = threadIdx.x & (WAVE - 1);
+#ifdef RN_HIDDEN_ARG_DIMS
     const int b = xcd_block(blockIdx.x, gridDim.x);
+    const int r = uniform(b * (int)(blockDim.x >> 6) + (threadIdx.x >> 6));
+#else
+    const int b = xcd_block(blockIdx.x, (n + WPB - 1) / WPB);
     // the wave's ray index lives in an SGPR (the compiler cannot see that threadIdx.x >> 6 is
     // wave-uniform): row addresses become scalar base + per-lane 32-bit offset
-    const int r = uniform(b * (int)(blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int r = uniform(b * WPB + (int)(threadIdx.x >> 6));
+#endif
     return r < n ? r : -1;
 }
 

@@ -42,7 +42,10 @@ __device__ __forceinline__ float gather_acc(const float *__restrict__ acc, int l
 // costs instructions whether or not the ray reaches it -- measured, k_bp sits at its
 // VALU-issue floor (SQ_INSTS_VALU x 4 cycles), so instructions are what there is to save.
 // (Also measured and dropped: walking several rays per wavefront with the next ray's rows in
-// flight -- no gain, the limit was never the dependent round trips.)
+// flight; requesting the first 64 entries of the rows before the ray's count is known; all
+// kernel arguments in one scalar fetch up front -- no gain, the limit was never the dependent
+// round trips (profiles/r02_exp_wave_startup.txt).  What did help is not reading gridDim /
+// blockDim at all: ray_of_wave.)
 template <int NCH>
 struct RayRows {
     float sv[NCH], mv[NCH];
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_bp(Params p, int n, const floa
                                               const float *msgs_in, float *msgs_out,
                                               int uniform_acc) {
     int lane;
-    const int r = ray_of_wave(n, lane);
+    const int r = ray_of_wave<RN_RAY_BLOCK>(n, lane);
     if (r < 0) return;
     const int count = min(uniform(rvc[r]), p.M);
     if (count <= 1) return;   // mrf_np.py:300: such rays send nothing
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const f
                                                  const float *__restrict__ cc, float *S_new,
                                                  float *depth_map, int rays_per_center) {
     int lane;
-    const int r = ray_of_wave(n, lane);
+    const int r = ray_of_wave<RN_RAY_BLOCK>(n, lane);
     if (r < 0) return;
     if (rays_per_center > 0 && cc) cc += 4 * (r / rays_per_center);
     const int count = min(uniform(rvc[r]), p.M);

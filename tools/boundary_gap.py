@@ -48,3 +48,34 @@ prev = rows[idx[-2]][1]
 for name, t in rows[idx[-2]:]:
     print("%-15s %9.3f ms  (+%.3f)" % (name, t, t - prev))
     prev = t
+
+# the prologue of a pass, piece by piece (host time, cached plan)
+import raynet_amd.forward_pass as F
+refs = list(range(V))
+def timeit(f, n=200):
+    t = time.perf_counter()
+    for _ in range(n):
+        r = f()
+    return (time.perf_counter() - t) / n * 1e6, r
+us, bank_ = timeit(lambda: fp._view_features(scene, refs))
+print("_view_features        %7.1f us" % us)
+Fdim = next(iter(bank_.values())).shape[-1]
+us, ctx_ = timeit(lambda: fp._context(scene, Fdim))
+print("_context              %7.1f us" % us)
+us, bank2 = timeit(lambda: {v: f.to(ctx_.device, torch.float32).contiguous() for v, f in bank_.items()})
+print("bank .to().contiguous %7.1f us" % us)
+us, _ = timeit(lambda: fp._prior())
+print("_prior                %7.1f us" % us)
+d = F._dist()
+us, plan = timeit(lambda: fp._build_plan(scene, refs, bank2, ctx_, *d))
+print("_build_plan (cached)  %7.1f us" % us)
+us, _ = timeit(lambda: F._dist())
+print("_dist                 %7.1f us" % us)
+us, _ = timeit(lambda: torch.cuda.current_stream(ctx_.device).wait_stream(fp._side_stream))
+print("wait_stream(side)     %7.1f us" % us)
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(200):
+    fp._build_plan(scene, refs, bank2, ctx_, *d)
+pr.disable()
+pstats.Stats(pr).sort_stats("cumtime").print_stats(12)
