@@ -476,6 +476,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     p.H = cfg->H; p.W = cfg->W; p.padding = cfg->padding;
     p.gx = cfg->grid[0]; p.gy = cfg->grid[1]; p.gz = cfg->grid[2];
     p.nby = (p.gy + 3) / 4; p.nbz = (p.gz + 3) / 4;
+    p.plane_step = (1.0f - 0.0f) / (p.D - 1);
     p.Hf = cfg->H + cfg->padding + 1;
     p.Wf = cfg->W + cfg->padding + 1;
     for (int i = 0; i < 6; i++) p.bbox[i] = cfg->bbox[i];

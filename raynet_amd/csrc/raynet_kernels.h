@@ -29,6 +29,7 @@ struct Params {
     int gx, gy, gz;
     int nby, nbz;        // 4x4x4 bricks along y and z (resident accumulator layout)
     int Hf, Wf;          // feature map extent: H+padding+1, W+padding+1
+    float plane_step;    // (1.0f - 0.0f) / (D - 1) of planes_voxels_mapping.cu, divided on the host
     float bbox[6];
 };
 
@@ -155,7 +156,7 @@ __device__ __forceinline__ float round_half_away(float x) {
 // divisor an infinite one): reciprocal_is_normal, one v_cmp_class per divisor.  The caller
 // takes the IEEE division when it is not sure; rn_selftest_quotient puts the two side by side.
 __device__ __forceinline__ bool reciprocal_is_normal(float rcp_n) {
-    return __builtin_amdgcn_class(rcp_n, 0x108);     // -normal | +normal
+    return __builtin_amdgcn_classf(rcp_n, 0x108);    // -normal | +normal (v_cmp_class_f32)
 }
 __device__ __forceinline__ float round_quotient_fast(float x, float rcp_n, bool &sure) {
     const float q = x * rcp_n;
@@ -558,7 +559,10 @@ __host__ __device__ __forceinline__ int slab_box_count(int M) {
 //     evaluated with the same fp32 expressions, so the plane indices are exact;
 //   * vals[] (LDS, M floats) receives the un-normalised interpolation, the sum
 //     is returned wave-uniform.
-template <bool PACKED, bool FAST = false>
+//   * STAGED: the caller parked the ray's packed ids in vals[0 .. count) (k_sweep_map's
+//     LDS-DMA); a run-time choice between that and the global row turns the load into a flat
+//     load of a selected pointer.
+template <bool PACKED, bool FAST = false, bool STAGED = false>
 __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
                                                       const float *__restrict__ axes,
                                                       const int32_t *__restrict__ vrow,
@@ -571,7 +575,7 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
     for (int i = 0; i < 3; i++) ray[i] = e[i] - s[i];
 #pragma unroll
     for (int i = 0; i < 3; i++) ray_norm += ray[i] * ray[i];
-    const float step = (1.0f - 0.0f) / (p.D - 1);
+    const float step = p.plane_step;       // the same IEEE quotient, once per context
     int carry = 0;
     float total = 0.0f;
     for (int base = 0; base < count; base += WAVE) {
@@ -581,7 +585,7 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
         float t = 0.0f;
         if (valid) {
             int x, y, z;
-            if (PACKED && i < n_staged) {       // packed ids parked in vals[] by the caller
+            if (PACKED && STAGED) {
                 const int v = __builtin_bit_cast(int, vals[i]);
                 x = v >> 20;
                 y = (v >> 10) & 1023;

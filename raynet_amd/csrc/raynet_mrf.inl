@@ -21,15 +21,37 @@ __device__ __forceinline__ int load_packed(const int32_t *__restrict__ row, int 
 // a brick in a row, so the 64 gathers of a wavefront instruction fall into ~16 cache lines
 // instead of 64 when the ray does not travel along z.  Measured: the gather is the largest
 // single cost of k_bp (no gather: -37 %); bricks take half of it back.
+// a * b + c on 24-bit operands (b wave-uniform): the full-rate v_mad_u32_u24.  Written out
+// because the compiler, not knowing the range of a kernel argument, takes `a * b + c` (and
+// __umul24) to the quarter-rate v_mad_u64_u32.
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b_uniform, unsigned c) {
+    unsigned d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+}
+// entry of a voxel in a workgroup's LDS box (d1, d2 wave-uniform extents, all < 1024)
+__device__ __forceinline__ unsigned box_index(int dx, int dy, int dz, int d1, int d2) {
+    return mad_u24(mad_u24((unsigned)dx, (unsigned)d1, (unsigned)dy), (unsigned)d2, (unsigned)dz);
+}
 template <bool BRICK>
 __device__ __forceinline__ int lin_xyz(const Params &p, int x, int y, int z) {
+    // 24-bit multiplies: coordinates < 1024, 256 bricks per axis at most
     if (BRICK)
-        return ((((x >> 2) * p.nby + (y >> 2)) * p.nbz + (z >> 2)) << 6) | ((x & 3) << 4) |
-               ((y & 3) << 2) | (z & 3);
+        return (int)((mad_u24(mad_u24((unsigned)x >> 2, (unsigned)p.nby, (unsigned)y >> 2),
+                              (unsigned)p.nbz, (unsigned)z >> 2) << 6) |
+                     ((x & 3) << 4) | ((y & 3) << 2) | (z & 3));
     return (x * p.gy + y) * p.gz + z;
 }
 template <bool BRICK>
 __device__ __forceinline__ int lin_of(const Params &p, int v) {
+    if (BRICK) {
+        // straight from the packed word: 8-bit brick coordinates (provably 24-bit operands for
+        // the multiplies) and the three 2-bit offsets inside the brick
+        const unsigned u = (unsigned)v;
+        const unsigned b = mad_u24(mad_u24((u >> 22) & 255u, (unsigned)p.nby, (u >> 12) & 255u),
+                                   (unsigned)p.nbz, (u >> 2) & 255u);
+        return (int)((b << 6) | ((u >> 16) & 48u) | ((u >> 8) & 12u) | (u & 3u));
+    }
     return lin_xyz<BRICK>(p, v >> 20, (v >> 10) & 1023, v & 1023);
 }
 __device__ __forceinline__ float gather_acc(const float *__restrict__ acc, int lin) {
@@ -666,7 +688,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
 #ifdef RN_EXP_BOX_NOLDS         // timing experiment only (wrong results): no LDS atomics
                     asm volatile("" ::"v"(((x - lo0) * d1 + (y - lo1)) * d2 + (z - lo2)), "v"(m[k]));
 #else
-                    __hip_atomic_fetch_add(box + ((x - lo0) * d1 + (y - lo1)) * d2 + (z - lo2),
+                    __hip_atomic_fetch_add(box + box_index(x - lo0, y - lo1, z - lo2, d1, d2),
                                            Sum::from_msg(m[k]), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
@@ -709,7 +731,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                     const int pv = load_packed<PACKED>(vox + row * (PACKED ? 1 : 3), st);
                     const int x = pv >> 20, y = (pv >> 10) & 1023, z = pv & 1023;
                     if (fits)
-                        __hip_atomic_fetch_add(box + ((x - lo0) * e1 + (y - lo1)) * e2 + (z - lo2),
+                        __hip_atomic_fetch_add(box + box_index(x - lo0, y - lo1, z - lo2, e1, e2),
                                                Sum::from_msg(mm), __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
                     else

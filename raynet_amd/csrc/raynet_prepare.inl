@@ -379,8 +379,8 @@ void k_sweep_map(
     // MAPMODE 2 = the resident path: value-only divisions through the hardware reciprocal
     // (the plane index walk inside stays IEEE); MAPMODE 1 = K6 / K11, reference arithmetic
     const float srsum =
-        map_planes_to_voxels<PACKED, MAPMODE == 2>(p, axes, vrow, count, s, e, Sl, vals, lane,
-                                                   n_staged);
+        map_planes_to_voxels<PACKED, MAPMODE == 2, PACKED>(p, axes, vrow, count, s, e, Sl, vals,
+                                                           lane, n_staged);
     RN_PHASE_MARK(4);                      // planes -> voxels
     if (MAPMODE == 1) {
         for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
