@@ -56,8 +56,12 @@ __device__ __forceinline__ int dpp_i(int old, int src) {
 // instructions per step for mul / max and for the two row_bcast steps of add (materialise
 // the identity, v_mov_dpp, op).  `s_nop 1`
 // covers the VALU-write -> DPP-read hazard, which the assembler does not insert inside asm.
+#ifdef RN_EXP_NO_DPP_NOPS     // timing experiment only (WRONG results: the hazard is real)
+#define RN_SCAN_STEP(OP, X, CTRL) asm(OP " %0, %0, %0 " CTRL : "+v"(X))
+#else
 #define RN_SCAN_STEP(OP, X, CTRL) \
     asm("s_nop 1\n\t" OP " %0, %0, %0 " CTRL : "+v"(X))
+#endif
 #define RN_WAVE_SCAN(OP, X)                                             \
     RN_SCAN_STEP(OP, X, "row_shr:1 row_mask:0xf bank_mask:0xf");        \
     RN_SCAN_STEP(OP, X, "row_shr:2 row_mask:0xf bank_mask:0xf");        \
@@ -84,11 +88,14 @@ __device__ __forceinline__ float wave_shift1(float x, float first) {
 // suffix[i] = sum_{j>i} x[j] within the wavefront (exclusive reverse scan); also returns
 // the wave total through `total`
 __device__ __forceinline__ float wave_suffix_excl(float x, int lane, float &total) {
-    const float y = __shfl(x, 63 - lane);          // reverse lane order
+    // reverse lane order: ds_bpermute with the byte address of lane 63 - i (__shfl would
+    // rebuild the lane id with two v_mbcnt and mask it for its width argument every time)
+    const int rev = (63 - lane) << 2;
+    const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rev, __builtin_bit_cast(int, x)));
     const float incl = wave_scan_add(y);
     total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
     const float excl = dpp_f<0x138, 0xf>(0.0f, incl);
-    return __shfl(excl, 63 - lane);
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rev, __builtin_bit_cast(int, excl)));
 }
 __device__ __forceinline__ float lane63(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));

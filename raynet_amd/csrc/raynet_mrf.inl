@@ -68,6 +68,9 @@ __device__ __forceinline__ float gather_acc(const float *__restrict__ acc, int l
 // kernel arguments in one scalar fetch up front -- no gain, the limit was never the dependent
 // round trips (profiles/r02_exp_wave_startup.txt).  What did help is not reading gridDim /
 // blockDim at all: ray_of_wave.)
+#ifndef RN_BP_NT
+#define RN_BP_NT true
+#endif
 template <int NCH>
 struct RayRows {
     float sv[NCH], mv[NCH];
@@ -77,19 +80,22 @@ struct RayRows {
 // uniform base + a 32-bit byte offset per lane (global_load_dword v, v_off, s[base:base+1]):
 // no 64-bit address arithmetic on the VALU, which is what these kernels are short of.
 typedef const __attribute__((address_space(1))) char *gbytes;
-template <typename T>
+// NT: streamed once by this kernel -- kept out of the L2 ways the accumulator gathers live in
+template <bool NT = false, typename T>
 __device__ __forceinline__ T row_load(const T *row_uniform, unsigned i) {
     typedef const __attribute__((address_space(1))) T *gT;
+    if (NT) return __builtin_nontemporal_load((gT)((gbytes)row_uniform + i * (unsigned)sizeof(T)));
     return *(gT)((gbytes)row_uniform + i * (unsigned)sizeof(T));
 }
-template <typename T>
+template <bool NT = false, typename T>
 __device__ __forceinline__ void row_store(T *row_uniform, unsigned i, T v) {
     typedef __attribute__((address_space(1))) T *gT;
     typedef __attribute__((address_space(1))) char *gb;
-    *(gT)((gb)row_uniform + i * (unsigned)sizeof(T)) = v;
+    if (NT) __builtin_nontemporal_store(v, (gT)((gb)row_uniform + i * (unsigned)sizeof(T)));
+    else *(gT)((gb)row_uniform + i * (unsigned)sizeof(T)) = v;
 }
 // the first `count` entries of the ray's column, voxel list and (optionally) messages
-template <int NCH, bool PACKED>
+template <int NCH, bool PACKED, bool NT = false>
 __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
                                           const float *__restrict__ S,
                                           const int32_t *__restrict__ vox, const float *msgs, int r,
@@ -107,12 +113,12 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
 #ifdef RN_EXP_NO_SR
             R.sv[ch] = 1.0f / count;
 #else
-            R.sv[ch] = row_load(Srow, (unsigned)i);
+            R.sv[ch] = row_load<NT>(Srow, (unsigned)i);
 #endif
-            if (PACKED) R.pk[ch] = row_load(vrow, (unsigned)i);
+            if (PACKED) R.pk[ch] = row_load<NT>(vrow, (unsigned)i);
             else R.pk[ch] = load_packed<PACKED>(vrow, i);
 #ifndef RN_EXP_NO_MSG
-            if (mrow) R.mv[ch] = row_load(mrow, (unsigned)i);
+            if (mrow) R.mv[ch] = row_load<NT>(mrow, (unsigned)i);
 #endif
         }
     }
@@ -155,7 +161,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
                                        const float *__restrict__ acc_in, const float *msgs_in,
                                        float *msgs_out, bool uniform_acc) {
     RayRows<NB> cur;
-    load_rows<NB, PACKED>(p, cur, S, vox, msgs_in, r, count, lane);
+    load_rows<NB, PACKED, RN_BP_NT>(p, cur, S, vox, msgs_in, r, count, lane);
     // accumulator gather (depends on the voxel rows).  uniform_acc: every voxel holds
     // acc_in[0] (the first iteration starts from the prior everywhere) -- nothing to gather,
     // and with zero messages on top the occupancy is one constant for the whole sweep.
@@ -165,11 +171,33 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
     for (int ch = 0; ch < NB; ch++) {
         const int i = ch * WAVE + lane;
         av[ch] = a0;
+#ifndef RN_EXP_BP_NOGATHER      // timing experiments only (wrong results), as the ones below
         if (!uniform_acc && ch * WAVE < count && i < count)
             av[ch] = gather_acc(acc_in, lin_of<PACKED>(p, cur.pk[ch]));
+#else
+        av[ch] = __builtin_bit_cast(float, cur.pk[ch]) * 1e-30f;
+#endif
     }
+#ifdef RN_EXP_BP_NOCOMPUTE
+    {
+        float *mo = msgs_out + (size_t)r * p.M;
+#pragma unroll
+        for (int ch = 0; ch < NB; ch++) {
+            const int i = ch * WAVE + lane;
+            if (ch * WAVE < count && i < count) row_store(mo, (unsigned)i, cur.sv[ch] + cur.mv[ch] + av[ch]);
+        }
+        return;
+    }
+#endif
+    // const_o (iteration 0 of a pass: the prior everywhere, no messages yet): one occupancy
+    // for the whole sweep.  Real (uniform) branches on it: as selects, every ray pays for the
+    // constant's exponential AND every chunk for the per-voxel ones, whichever is used.
     const bool const_o = uniform_acc && msgs_in == nullptr;
-    const float o_const = occupancy_to_ray(a0, 0.0f);
+    float o_const = 0.0f;
+    if (const_o) {
+        asm volatile("" ::: "memory");      // (keeps the branch a branch)
+        o_const = occupancy_to_ray(a0, 0.0f);
+    }
     float *mout_row = msgs_out + (size_t)r * p.M;
     clip_renorm_rows<NB, CLIP_IN>(cur.sv, count, lane);
 
@@ -183,7 +211,10 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
             const int i = ch * WAVE + lane;
             const bool valid = i < count;
             float o = o_const;
-            if (!const_o) o = occupancy_to_ray(av[ch], cur.mv[ch]);
+            if (!const_o) {
+                asm volatile("" ::: "memory");
+                o = occupancy_to_ray(av[ch], cur.mv[ch]);
+            }
             if (!valid) o = 0.0f;
             const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
             const float T = carryT * wave_shift1(incl, 1.0f);
@@ -227,7 +258,11 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
                 const float pos = cex[ch] + tsv[ch];
                 const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
                 const float m = bp_log(pos) - bp_log(neg);
-                row_store(mout_row, (unsigned)i, m);
+#ifdef RN_EXP_BP_NOSTORE
+                if (m == 123.456f) row_store(mout_row, (unsigned)i, m);
+#else
+                row_store<RN_BP_NT>(mout_row, (unsigned)i, m);
+#endif
             }
         }
     }

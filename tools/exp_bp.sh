@@ -1,8 +1,13 @@
+# what k_bp's time is made of: timing-only builds (wrong results on purpose)
 cd $GRAFT_REPO_ROOT
 cp raynet_amd/csrc/libraynet_hip.so /tmp/lib_orig.so
-for v in "uniform_r:" "fast_occ_exp:-DRN_FAST_OCC_EXP" "uniform_r:" "fast_occ_exp:-DRN_FAST_OCC_EXP"; do
-  bash tools/ab_flags.sh "${v%%:*}" "${v#*:}"
-done
-# parity with the fast exponential in place
-timeout 900 python -m pytest tests/test_saturated_golden.py tests/test_hip_parity_gpu.py tests/test_forward_pass_gpu.py tests/test_mrf_backward_gpu.py -q -m gpu 2>&1 | tail -8
+bash tools/ab_flags.sh "as is                        " ""
+bash tools/ab_flags.sh "no message store             " "-DRN_EXP_BP_NOSTORE"
+bash tools/ab_flags.sh "no accumulator gather        " "-DRN_EXP_BP_NOGATHER"
+bash tools/ab_flags.sh "no gather, no store          " "-DRN_EXP_BP_NOGATHER -DRN_EXP_BP_NOSTORE"
+bash tools/ab_flags.sh "loads + gather + store only  " "-DRN_EXP_BP_NOCOMPUTE"
+bash tools/ab_flags.sh "loads + store only           " "-DRN_EXP_BP_NOCOMPUTE -DRN_EXP_BP_NOGATHER"
+bash tools/ab_flags.sh "no Sr, no msg read           " "-DRN_EXP_NO_SR -DRN_EXP_NO_MSG"
+bash tools/ab_flags.sh "compute only (no rows but vox, no gather, no store)" "-DRN_EXP_NO_SR -DRN_EXP_NO_MSG -DRN_EXP_BP_NOGATHER -DRN_EXP_BP_NOSTORE"
+bash tools/ab_flags.sh "as is                        " ""
 cp /tmp/lib_orig.so raynet_amd/csrc/libraynet_hip.so
