@@ -18,6 +18,38 @@ __global__ __launch_bounds__(256) void k(int n, const int *__restrict__ cnt, con
         if (nt) __builtin_nontemporal_store(x, d + o + i); else d[o + i] = x;
     }
 }
+// the same, and before it ends every wavefront requests the rows of ray r + K (results
+// unused): a later wavefront then finds its rows in the L2 -- a prefetch ACROSS wavefronts that
+// costs no registers in the wavefront that profits
+__global__ __launch_bounds__(256) void kp(int n, const int *__restrict__ cnt, const long long *__restrict__ off,
+                                          const float *__restrict__ a, const int *__restrict__ b,
+                                          const float *__restrict__ c, float *d, int nt, int K) {
+    const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (r >= n) return;
+    const int lane = threadIdx.x & 63, count = cnt[r];
+    const long long o = off[r];
+    const int rp = r + K;
+    int cp = 0; long long op = 0;
+    if (rp < n) { cp = cnt[rp]; op = off[rp]; }
+    for (int i = lane; i < count; i += 64) {
+        float x = a[o + i] + c[o + i] + (float)b[o + i];
+        if (nt) __builtin_nontemporal_store(x, d + o + i); else d[o + i] = x;
+    }
+    // 16 bytes per lane: lanes 0 .. ceil(cp / 4) - 1 cover the future ray's rows
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 pa, pb, pc;
+    bool did = false;
+    if (4 * lane < cp) {
+        const v4 *qa = reinterpret_cast<const v4 *>(a + op) + lane;
+        const v4 *qb = reinterpret_cast<const v4 *>(b + op) + lane;
+        const v4 *qc = reinterpret_cast<const v4 *>(c + op) + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pa) : "v"(qa));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pb) : "v"(qb));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pc) : "v"(qc));
+        did = true;
+    }
+    if (did) asm volatile("" ::"v"(pa), "v"(pb), "v"(pc));   // keeps the registers reserved to the end
+}
 int main() {
     const int n = 1536000, M = 384;
     std::vector<int> cnt(n); std::vector<long long> offs(n), offc(n);
@@ -40,6 +72,15 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
         printf("%s rows, %s stores: %.3f ms, %.0f GB/s (12 B read + 4 B written per entry)\n", layout ? "packed " : "strided", nt ? "non-temporal" : "plain       ", ms, used * 16 / ms / 1e6);
+    }
+    hipMemcpy(doff, offs.data(), n * 8, hipMemcpyHostToDevice);
+    for (int K : {0, 256, 1024, 4096, 16384}) {
+        for (int w = 0; w < 2; w++) hipLaunchKernelGGL(kp, dim3((n + 3) / 4), dim3(256), 0, 0, n, dcnt, doff, a, b, c, d, 1, K ? K : n);
+        hipEventRecord(e0);
+        for (int w = 0; w < 10; w++) hipLaunchKernelGGL(kp, dim3((n + 3) / 4), dim3(256), 0, 0, n, dcnt, doff, a, b, c, d, 1, K ? K : n);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+        printf("strided rows, non-temporal stores, rows of ray r + %d requested ahead: %.3f ms, %.0f GB/s\n", K, ms, used * 16 / ms / 1e6);
     }
     return 0;
 }
