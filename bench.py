@@ -21,7 +21,9 @@ Prints ONE JSON line on rank 0.  Extra objects:
                the launch stream, via rn_prof_begin/rn_prof_end), vs the 8 TB/s HBM peak
   kernels      every family's share of a step, from up to 3 untimed steps before the timed
                region with every launch bracketed (the timed region brackets the dominant
-               family's launches only, unless --events all)
+               family's launches only, unless --events all): the sum of its launches'
+               durations, and its share of the timeline (concurrent launches on the second
+               stream split the time they overlap; the dominant family is chosen by this)
   cpu_baseline two legs on bounded ray samples of the same scene (rays of all reference
                images), on this box's host cores: "port" = the C oracle's fused K1/K2 path
                (the reference's algorithm, OpenMP over rays, all cores) -- also the object's
@@ -160,9 +162,26 @@ def main():
         step()
     fence()
     launches_all = ctx.prof_end()
+    # Which family dominates: by its SHARE of the timeline, not by the sum of its launches'
+    # durations -- with the second stream on (config 4: the scatter of one half of the rows next
+    # to k_bp of the other) concurrent launches would each be charged the whole overlap.  An
+    # instant with k launches in flight gives each of them 1 / k of it.
+    starts = list(getattr(ctx, "prof_starts", []))
     by_family = {}
-    for name, _, ms in launches_all:
-        by_family[name] = by_family.get(name, 0.0) + ms
+    if len(starts) == len(launches_all) and launches_all:
+        edges = sorted({t for (_, _, ms), st in zip(launches_all, starts) for t in (st, st + ms)})
+        iv = sorted((st, st + ms, name) for (name, _, ms), st in zip(launches_all, starts))
+        active, nxt = [], 0
+        for a, b in zip(edges[:-1], edges[1:]):
+            while nxt < len(iv) and iv[nxt][0] <= a:
+                active.append(iv[nxt])
+                nxt += 1
+            active = [x for x in active if x[1] > a]
+            for x in active:
+                by_family[x[2]] = by_family.get(x[2], 0.0) + (b - a) / len(active)
+    else:
+        for name, _, ms in launches_all:
+            by_family[name] = by_family.get(name, 0.0) + ms
     dominant = max((k for k in by_family if k != "acc"), key=lambda k: by_family[k], default=None)
     only = [dominant] if (args.events == "dominant" and dominant) else None
     ctx.prof_begin(capacity=64 * V * max(args.steps, 1) + 64, only=only)
@@ -230,6 +249,7 @@ def main():
                         avg_launch_ms=round(d["ms"] / d["launches"], 4), launches=d["launches"],
                         algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]))
     kernels = {k: dict(total_ms_per_step=round(v["ms"] / breakdown_steps, 3),
+                       timeline_share_ms_per_step=round(by_family.get(k, 0.0) / breakdown_steps, 3),
                        launches_per_step=v["launches"] / breakdown_steps,
                        algorithmic_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
                        if v["ms"] > 0 and v["bytes"] else None)
