@@ -84,6 +84,28 @@ def algorithmic_bytes(kernel, n_rays, voxels, cfg, images=1):
     return 0
 
 
+def timeline_shares(launches, starts):
+    """launches: (family, n_rays, duration ms) per launch; starts: its start (ms, one clock).
+    -> {family: ms}: an instant with k launches in flight gives each of them 1 / k of it.
+    Without start times: the plain sums of the durations."""
+    out = {}
+    if len(starts) != len(launches) or not launches:
+        for name, _, ms in launches:
+            out[name] = out.get(name, 0.0) + ms
+        return out
+    edges = sorted({t for (_, _, ms), st in zip(launches, starts) for t in (st, st + ms)})
+    iv = sorted((st, st + ms, name) for (name, _, ms), st in zip(launches, starts))
+    active, nxt = [], 0
+    for a, b in zip(edges[:-1], edges[1:]):
+        while nxt < len(iv) and iv[nxt][0] <= a:
+            active.append(iv[nxt])
+            nxt += 1
+        active = [x for x in active if x[1] > a]
+        for x in active:
+            out[x[2]] = out.get(x[2], 0.0) + (b - a) / len(active)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,22 +188,7 @@ def main():
     # durations -- with the second stream on (config 4: the scatter of one half of the rows next
     # to k_bp of the other) concurrent launches would each be charged the whole overlap.  An
     # instant with k launches in flight gives each of them 1 / k of it.
-    starts = list(getattr(ctx, "prof_starts", []))
-    by_family = {}
-    if len(starts) == len(launches_all) and launches_all:
-        edges = sorted({t for (_, _, ms), st in zip(launches_all, starts) for t in (st, st + ms)})
-        iv = sorted((st, st + ms, name) for (name, _, ms), st in zip(launches_all, starts))
-        active, nxt = [], 0
-        for a, b in zip(edges[:-1], edges[1:]):
-            while nxt < len(iv) and iv[nxt][0] <= a:
-                active.append(iv[nxt])
-                nxt += 1
-            active = [x for x in active if x[1] > a]
-            for x in active:
-                by_family[x[2]] = by_family.get(x[2], 0.0) + (b - a) / len(active)
-    else:
-        for name, _, ms in launches_all:
-            by_family[name] = by_family.get(name, 0.0) + ms
+    by_family = timeline_shares(launches_all, list(getattr(ctx, "prof_starts", [])))
     dominant = max((k for k in by_family if k != "acc"), key=lambda k: by_family[k], default=None)
     only = [dominant] if (args.events == "dominant" and dominant) else None
     ctx.prof_begin(capacity=64 * V * max(args.steps, 1) + 64, only=only)

@@ -822,3 +822,36 @@ def test_resident_path_odd_shapes_vs_oracle(torch, oracle_mod, D, M, grid, nb):
         m = np.zeros((H * W, M), np.float32)
         m[fp.ray_index[r].cpu().numpy().astype(np.int64)] = fp.messages[r].cpu().numpy()
         assert np.abs(m - msgs[r]).max() <= 1e-4
+
+
+def test_per_launch_profiling_and_family_selection(torch):
+    """rn_prof_begin / rn_prof_select / rn_prof_end: every launch of a pass is bracketed; with a
+    family selected only its launches are; start offsets and durations are consistent."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W, D, M, grid = 24, 32, 16, 96, (32, 32, 32)
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    fp = get_forward_pass_factory("raynet")(bank, _gp(D, M, grid), "sample_in_bbox", (H, W), 0)
+    refs = (0, 3, 1)
+    ref_maps = list(fp.forward_pass(scene, refs))
+    ctx = fp._ctx
+    ctx.prof_begin(capacity=256)
+    maps = list(fp.forward_pass(scene, refs))
+    everything = ctx.prof_end()
+    starts = list(ctx.prof_starts)
+    names = [n for n, _, _ in everything]
+    # one traversal, one plane sweep, 3 x (bp, scatter, combine), one depth sweep per image
+    assert names.count("sweep_map") == 1 and names.count("traverse") == 1
+    assert names.count("bp") == 3 and names.count("scatter") == 3 and names.count("depth") == 3
+    assert all(ms > 0 for _, _, ms in everything) and len(starts) == len(everything)
+    assert starts[0] == 0.0 and all(b >= a for a, b in zip(starts, starts[1:]))
+    assert [r for n, r, _ in everything if n == "sweep_map"] == [3 * H * W]
+    ctx.prof_begin(capacity=256, only=["bp"])
+    list(fp.forward_pass(scene, refs))
+    only_bp = ctx.prof_end()
+    assert [n for n, _, _ in only_bp] == ["bp"] * 3
+    ctx.prof_begin(capacity=256)                   # the selection does not stick
+    list(fp.forward_pass(scene, refs))
+    assert len(ctx.prof_end()) == len(everything)
+    for a, b in zip(ref_maps, maps):               # profiling changes nothing but the timing
+        assert np.mean(np.abs(a - b) > 1e-4) < 0.01     # (float atomics: near-ties may flip)

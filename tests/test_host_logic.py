@@ -60,3 +60,24 @@ def test_shard_bounds_cover_the_list():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+def test_bench_timeline_shares_split_concurrent_launches():
+    """bench.py picks the dominant kernel family by its share of the timeline: launches that
+    overlap on two streams split the time they share, sequential ones keep their durations."""
+    import importlib.util
+    import os
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # a: [0, 2), b: [1, 3) on another stream, c: [3, 4)
+    launches = [("a", 0, 2.0), ("b", 0, 2.0), ("c", 0, 1.0)]
+    shares = bench.timeline_shares(launches, [0.0, 1.0, 3.0])
+    assert shares == pytest.approx({"a": 1.5, "b": 1.5, "c": 1.0})
+    assert sum(shares.values()) == pytest.approx(4.0)          # the union of the intervals
+    # same family twice, back to back: plain sum
+    assert bench.timeline_shares([("a", 0, 1.0), ("a", 0, 2.0)], [0.0, 1.0]) == pytest.approx({"a": 3.0})
+    # no start times: sums of durations
+    assert bench.timeline_shares(launches, []) == pytest.approx({"a": 2.0, "b": 2.0, "c": 1.0})
+    assert bench.timeline_shares([], []) == {}
