@@ -295,7 +295,13 @@ inline int2 *slab_boxes_for(const rn_ctx *ctx, const int32_t *vox, int64_t n, bo
 // workgroups per box-scatter tile (grid.y): enough of them for ~16 per CU
 inline int box_split(int n, int tile_rays) {
     const int tiles = (n + tile_rays - 1) / tile_rays;
-    return max(1, min(4, 4096 / max(tiles, 1)));
+#ifndef RN_BOX_SPLIT_TARGET
+#define RN_BOX_SPLIT_TARGET 4096
+#endif
+#ifndef RN_BOX_SPLIT_MAX
+#define RN_BOX_SPLIT_MAX 4
+#endif
+    return max(1, min(RN_BOX_SPLIT_MAX, RN_BOX_SPLIT_TARGET / max(tiles, 1)));
 }
 
 // One BP sweep: k_bp (messages) + the accumulator scatter that fits the row layout.
