@@ -206,6 +206,31 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                                                          hi0 < 0 ? -1 : pack_voxel(hi0, hi1, hi2));
         }
         // flush: TRAV_TILE consecutive steps of one ray are one contiguous segment
+#ifndef RN_TRAV_SCALAR_FLUSH
+        if (PACKED && TRAV_TILE == 16 && (p.M & 3) == 0) {
+            // four steps per lane and store (16-byte aligned: M and the tile base are multiples
+            // of 4): 4 store rounds per tile instead of 16; a row's last, partial group of four
+            // is written entry by entry -- nothing beyond a ray's count is touched
+#pragma unroll
+            for (int j = 0; j < WAVE; j += WAVE / 4) {
+                const int row = j + (lane >> 2), q4 = (lane & 3) * 4;
+                const int nv = min(__shfl(count, row) - base - q4, 4);
+                if (r0 + row < n && nv > 0) {
+                    const int32_t *t = tile + row * (TRAV_TILE + 1) + q4;
+                    int32_t *dst = vox + (size_t)(r0 + row) * p.M + base + q4;
+                    if (nv == 4) {
+                        *reinterpret_cast<int4 *>(dst) = make_int4(t[0], t[1], t[2], t[3]);
+                    } else {
+                        dst[0] = t[0];
+                        if (nv > 1) dst[1] = t[1];
+                        if (nv > 2) dst[2] = t[2];
+                    }
+                }
+            }
+            wave_sync();
+            continue;
+        }
+#endif
         constexpr int RPI = WAVE / TRAV_TILE;      // rows per instruction
 #pragma unroll 4
         for (int j = 0; j < WAVE; j += RPI) {
