@@ -192,11 +192,19 @@ def main():
     dominant = max((k for k in by_family if k != "acc"), key=lambda k: by_family[k], default=None)
     only = [dominant] if (args.events == "dominant" and dominant) else None
     ctx.prof_begin(capacity=64 * V * max(args.steps, 1) + 64, only=only)
+    # the interpreter's cyclic garbage collector is a property of the host process, not of the
+    # path: a generation-2 collection of a process that has imported torch pauses it for ~40 ms,
+    # once every ~20 passes (tools/step_jitter.py) -- five steps' worth landing in whichever
+    # timed region happens to contain it.  Collected before, off inside, back on after.
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     launches = ctx.prof_end()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

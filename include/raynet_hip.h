@@ -75,6 +75,26 @@ typedef struct rn_ctx rn_ctx;
  * configuration and creates a context. */
 int rn_create(const rn_config *cfg, rn_ctx **out);
 void rn_destroy(rn_ctx *ctx);
+
+/* Behaviour options of a context -- schedule and A/B knobs; no result depends on them beyond
+ * the summation order of the accumulator scatter.  The Python mirror is
+ * raynet_amd.hip_implementations.options.PathOptions; the reference has no counterpart (its
+ * only launch knob is `threads=2048`, raynet_fp.py:288).  rn_create starts from the defaults
+ * below, overridden by the environment variables named here (read there and nowhere else). */
+typedef struct {
+    int32_t scatter_mode;   /* -1 by row layout (default), 0 slab scatter, 2 LDS-box scatter
+                               [RAYNET_HIP_SCATTER_MODE] */
+    int32_t box_level;      /* tile shape the adaptive box scatter starts from: 0 (default) 128
+                               rays x 32 steps, 1: 256 x 16, 2: slab scatter [RAYNET_HIP_BOX_LEVEL] */
+    int32_t box_pin;        /* != 0: stay at box_level [RAYNET_HIP_BOX_PIN] */
+    int32_t overlap;        /* second stream (scatter || BP halves, traversal || plane sweep): 0 off,
+                               1 on, 2 (default) when the scatter runs at level 1 [RAYNET_HIP_OVERLAP] */
+    int32_t generic_sweep;  /* != 0: the reference-order plane sweep even for F = 32
+                               [RAYNET_HIP_GENERIC_SWEEP] */
+} rn_options;
+int rn_get_options(const rn_ctx *ctx, rn_options *out);
+/* also restarts the adaptive scatter (rn_scatter_reset) */
+int rn_set_options(rn_ctx *ctx, const rn_options *opt);
 const char *rn_last_error(const rn_ctx *ctx);
 const char *rn_version(void);
 
@@ -173,7 +193,9 @@ int rn_fused_depth(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs, const float 
  * and the clipped+renormalised voxel-space column; the sweeps then stream it.
  * Results are those of K1/K2 called with the same inputs.
  *   vox  [n][M] i32  packed (x<<20 | y<<10 | z)
- *   Sr   [n][M] f32  clip_and_renorm(S_voxel) (mrf_bp.cu:103-111)
+ *   Sr   [n][M] f32  clip_and_renorm(S_voxel) (mrf_bp.cu:103-111); the row of a ray with
+ *                    rvc <= 1 is NOT written (such a ray sends no message and its depth is
+ *                    that of its only voxel, mrf_np.py:300: nothing reads its column)
  * features_views: N device pointers (HOST array), one [Hf][Wf][F] map per view,
  * so a bank of per-view feature maps needs no re-stacking per reference image.
  * order (optional, may be NULL): a permutation of 0..n-1; wavefront i of the plane
@@ -273,6 +295,11 @@ int rn_scene_bp_sweep_fixed(rn_ctx *ctx, int32_t n, const float *Sr, const int32
                             void *stream);
 int rn_acc_combine_fixed(rn_ctx *ctx, int64_t *acc_part_fixed, float prior, float *acc_out,
                          void *stream);
+/* The same on `count` elements of any slab of the accumulator: what a rank runs on ITS 1 / N of
+ * the voxels between a reduce-scatter of the fixed-point partials and the all-gather of the
+ * float accumulator (sharded combine; 3/4 of the all-reduce's bytes on the wire). */
+int rn_acc_combine_fixed_range(rn_ctx *ctx, int64_t *acc_part_fixed, int64_t count, float prior,
+                               float *acc_out, void *stream);
 /* acc_out = prior + sum over copies (+ optionally `extra`, e.g. nothing or a
  * peer's partial); the copies are zeroed for the next iteration. */
 int rn_acc_combine(rn_ctx *ctx, float *acc_part, float prior, float *acc_out, void *stream);
@@ -288,6 +315,54 @@ int rn_scene_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
                    const int32_t *rvc, const float *acc, const float *msgs,
                    const float *camera_center, int32_t rays_per_center, float *S_new,
                    float *depth_map, void *stream);
+
+/* ---- one pass as a PLAN (what RayNetForwardPass.forward_pass enqueues per step) ----------
+ * forward_pass.py:579-748 in the resident form: the caller describes the scene's buffers once
+ * and then runs whole phases of a pass with one call each -- the K1 prefix of all images, one BP
+ * iteration over all images, the depth sweep -- instead of one call per kernel.  Between the
+ * SWEEP phases of two iterations the caller runs its exchange (the all-reduce across GPUs of
+ * acc[iteration & 1], or of acc_fixed), nothing else.
+ *
+ * Accumulators.  Float mode: acc[0], acc[1] (rn_acc_size() floats each, bricked) hold the
+ * SUM of the messages only; the prior is added where an accumulator is read (`prior + sum`,
+ * the value rn_acc_combine would have stored -- bit for bit), so there is no combine kernel,
+ * and the sweep of iteration t clears acc[t & 1] itself before its scatter adds into it: no
+ * buffer has to be zeroed or refilled by the caller, ever (forward_pass.py:676-678's swap +
+ * fill(prior) costs nothing here).  Iteration 0 reads no accumulator (the prior everywhere).
+ * Deterministic mode: the scatter adds 31.32 fixed-point integers into acc_fixed (cleared by
+ * RN_RUN_PREPARE and by every RN_RUN_COMBINE), RN_RUN_COMBINE turns it into acc[t & 1] =
+ * prior + sum (a full log-odds accumulator), which iteration t + 1 reads as it is.
+ * The depth sweep reads acc[(iterations - 1) & 1]; with iterations == 0 that is acc[1], which
+ * the caller then sets itself (zeros in float mode, the prior in deterministic mode). */
+typedef struct {
+    int32_t n_images;              /* reference images of the pass                       */
+    int32_t n;                     /* rays per image (this rank's rows of every image)   */
+    int64_t rows_per_image;        /* image g owns rows [g*rows_per_image, +n); % 256 == 0 */
+    const int32_t *ray_idxs;       /* [n], shared by the images                          */
+    const int32_t *order;          /* optional schedule of the plane sweep, see rn_scene_prepare */
+    const float *const *features_views;  /* DEVICE [n_images][N] feature-map pointers    */
+    const float *cameras;          /* [n_images][12N + 16], see rn_scene_prepare_all     */
+    int32_t *vox;                  /* [n_images*rows_per_image][M]                       */
+    int32_t *rvc;                  /* [n_images*rows_per_image]                          */
+    float *Sr;                     /* [n_images*rows_per_image][M]                       */
+    float *msgs;                   /* [n_images*rows_per_image][M]                       */
+    float *ray_segments;           /* optional scratch [n_images*rows_per_image][8]      */
+    float *acc[2];                 /* see above                                          */
+    int64_t *acc_fixed;            /* deterministic mode only, else NULL                 */
+    float *depth;                  /* [n_images*rows_per_image]                          */
+    float prior;                   /* log(gamma / (1 - gamma)), forward_pass.py:533-538  */
+    int32_t row_layout;            /* rn_row_layout                                      */
+} rn_scene_plan;
+typedef enum {
+    RN_RUN_PREPARE = 1,   /* traversal + plane sweep + mapping of all images (rn_scene_prepare_all) */
+    RN_RUN_SWEEP = 2,     /* BP iteration `iteration` over all images: messages + scatter          */
+    RN_RUN_COMBINE = 4,   /* deterministic mode: acc[iteration & 1] = prior + acc_fixed            */
+    RN_RUN_DEPTH = 8      /* depth sweep of image `image` (all images in one launch if < 0) after
+                             `iteration` BP iterations                                             */
+} rn_run_phase;
+/* Runs the phases named in `phases` in the order PREPARE, SWEEP, COMBINE, DEPTH. */
+int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *plan, int32_t phases, int32_t iteration,
+                 int32_t image, void *stream);
 
 /* ---- measurement -------------------------------------------------------- */
 /* Per-launch hipEvent timing on the stream each kernel runs on.  Between

@@ -53,6 +53,28 @@ class Config(ctypes.Structure):
     ]
 
 
+class Options(ctypes.Structure):
+    # rn_options (include/raynet_hip.h)
+    _fields_ = [("scatter_mode", ctypes.c_int32), ("box_level", ctypes.c_int32),
+                ("box_pin", ctypes.c_int32), ("overlap", ctypes.c_int32),
+                ("generic_sweep", ctypes.c_int32)]
+
+
+class ScenePlan(ctypes.Structure):
+    # rn_scene_plan (include/raynet_hip.h)
+    _fields_ = [
+        ("n_images", ctypes.c_int32), ("n", ctypes.c_int32), ("rows_per_image", ctypes.c_int64),
+        ("ray_idxs", ctypes.c_void_p), ("order", ctypes.c_void_p),
+        ("features_views", ctypes.c_void_p), ("cameras", ctypes.c_void_p),
+        ("vox", ctypes.c_void_p), ("rvc", ctypes.c_void_p), ("Sr", ctypes.c_void_p),
+        ("msgs", ctypes.c_void_p), ("ray_segments", ctypes.c_void_p),
+        ("acc", ctypes.c_void_p * 2), ("acc_fixed", ctypes.c_void_p),
+        ("depth", ctypes.c_void_p), ("prior", ctypes.c_float), ("row_layout", ctypes.c_int32),
+    ]
+
+
+RN_RUN_PREPARE, RN_RUN_SWEEP, RN_RUN_COMBINE, RN_RUN_DEPTH = 1, 2, 4, 8
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int32
 _L = ctypes.c_int64
@@ -63,6 +85,9 @@ _F = ctypes.c_float
 SIGNATURES = {
     "rn_create": [ctypes.POINTER(Config), ctypes.POINTER(_P)],
     "rn_destroy": [_P],
+    "rn_get_options": [_P, ctypes.POINTER(Options)],
+    "rn_set_options": [_P, ctypes.POINTER(Options)],
+    "rn_scene_run": [_P, ctypes.POINTER(ScenePlan), _I, _I, _I, _P],
     "rn_last_error": [_P],
     "rn_version": [],
     "rn_set_voxel_grid": [_P, _P, _P],
@@ -96,6 +121,7 @@ SIGNATURES = {
     "rn_scene_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "rn_scene_bp_sweep_fixed": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "rn_acc_combine_fixed": [_P, _P, _F, _P, _P],
+    "rn_acc_combine_fixed_range": [_P, _P, _L, _F, _P, _P],
     "rn_acc_combine": [_P, _P, _F, _P, _P],
     "rn_acc_reduce_local": [_P, _P, _P, _P],
     "rn_acc_add_prior": [_P, _P, _F, _P],

@@ -24,7 +24,34 @@ constexpr int NXCD = 8;
 // XCD-aware remap: the dispatcher is observed to place block b on XCD b % 8; give
 // every XCD one contiguous slice of the ray list so its private L2 sees
 // neighbouring rays (speed only -- any placement is correct).
+// CHUNK = 0: every XCD gets one contiguous eighth of the list.  CHUNK > 0: chunks of CHUNK
+// consecutive work items stay on one XCD and the chunks go round the XCDs -- the XCDs then walk
+// the list side by side.  The work per item varies along the list (rays through the middle of
+// the box are long, border tiles are empty), so contiguous eighths leave some XCDs idle at the
+// end of a launch; what a kernel gains from locality decides its chunk
+// (profiles/r03_exp_xcd_chunk.txt): the plane sweep lives off neighbouring rays sharing feature
+// rows in L2 and wants its eighth, the scatter wants the balance.
+#ifndef RN_XCD_CHUNK_SWEEP
+#define RN_XCD_CHUNK_SWEEP 0
+#endif
+#ifndef RN_XCD_CHUNK_BP
+#define RN_XCD_CHUNK_BP 64
+#endif
+#ifndef RN_XCD_CHUNK_DEPTH
+#define RN_XCD_CHUNK_DEPTH 0
+#endif
+#ifndef RN_XCD_CHUNK_SCATTER
+#define RN_XCD_CHUNK_SCATTER 8
+#endif
+template <int CHUNK = 0>
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
+    if (CHUNK > 0) {
+        constexpr int C = CHUNK > 0 ? CHUNK : 1;
+        const int full = nblocks / (NXCD * C) * (NXCD * C);
+        if (b >= full) return b;
+        const int xcd = b % NXCD, pos = b / NXCD;
+        return ((pos / C) * NXCD + xcd) * C + pos % C;
+    }
     const int q = nblocks / NXCD, r = nblocks % NXCD;
     const int xcd = b % NXCD, pos = b / NXCD;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -36,15 +63,15 @@ __device__ __forceinline__ int xcd_block(int b, int nblocks) {
 // instead costs a wavefront that lives for ONE ray two more dependent fetches (the hidden
 // kernel arguments; blockDim even through the vector memory path) before its first row load:
 // k_depth -4 %, k_bp and k_sweep_map -1 % (profiles/r02_exp_wave_startup.txt).
-template <int BS = BLOCK>
+template <int BS = BLOCK, int CHUNK = 0>
 __device__ __forceinline__ int ray_of_wave(int n, int &lane) {
     constexpr int WPB = BS / WAVE;
     lane = threadIdx.x & (WAVE - 1);
 #ifdef RN_HIDDEN_ARG_DIMS
-    const int b = xcd_block(blockIdx.x, gridDim.x);
+    const int b = xcd_block<CHUNK>(blockIdx.x, gridDim.x);
     const int r = uniform(b * (int)(blockDim.x >> 6) + (threadIdx.x >> 6));
 #else
-    const int b = xcd_block(blockIdx.x, (n + WPB - 1) / WPB);
+    const int b = xcd_block<CHUNK>(blockIdx.x, (n + WPB - 1) / WPB);
     // the wave's ray index lives in an SGPR (the compiler cannot see that threadIdx.x >> 6 is
     // wave-uniform): row addresses become scalar base + per-lane 32-bit offset
     const int r = uniform(b * WPB + (int)(threadIdx.x >> 6));
@@ -138,7 +165,8 @@ struct rn_ctx {
     Params p;
     float *axes;          // device, gx+gy+gz
     bool have_axes;
-    int scatter_mode;     // A/B knob RAYNET_HIP_SCATTER_MODE: -1 by row layout (default), 0 slab, 2 LDS box
+    int scatter_mode;     // rn_options: -1 by row layout (default), 0 slab, 2 LDS box
+    int generic_sweep;    // rn_options: reference-order plane sweep even for F = 32
     // LDS-box scatter: level in use (launch_bp), {chunks, overflowed chunks} of the previous
     // launches on the device and its pinned host mirror
     int box_level, box_level0;
@@ -267,7 +295,7 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
         launch_sweep_t<0, 1, 8, MAPMODE, PACKED>(ctx, a, st);
         return;
     }
-    if (p.F == 32 && getenv("RAYNET_HIP_GENERIC_SWEEP") == nullptr) {
+    if (p.F == 32 && !ctx->generic_sweep) {
         switch (p.N) {
 #define RN_CASE(NV_)                                                  \
     case NV_:                                                         \
@@ -279,6 +307,11 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
         }
     }
     launch_sweep_t<1, 1, 8, MAPMODE, PACKED>(ctx, a, st);
+}
+
+// floats of one resident (bricked) accumulator: every axis padded to a multiple of 4
+inline int64_t acc_floats(const rn_ctx *ctx) {
+    return (int64_t)((ctx->p.gx + 3) / 4) * ctx->p.nby * ctx->p.nbz * 64;
 }
 
 // the slab-box rows that describe `vox` (a pointer into the bound list buffer), or null
@@ -305,15 +338,26 @@ inline int box_split(int n, int tile_rays) {
 }
 
 // One BP sweep: k_bp (messages) + the accumulator scatter that fits the row layout.
+// how a sweep reads its accumulator and what it clears on the side (the plan path, rn_scene_run)
+struct AccMode {
+    bool uniform = false;      // every voxel holds acc_in[0]
+    bool biased = false;       // acc_in holds sums only: the prior `bias` is added at the gather
+    float bias = 0.0f;
+    float *zero = nullptr;     // cleared by the FIRST k_bp launch of this call (rn_acc_size floats)
+};
+
 template <bool PACKED, bool CLIP_IN>
 void launch_bp_kernel(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
                       const float *acc_in, const float *msgs_in, float *msgs_out, hipStream_t st,
-                      bool uniform_acc) {
+                      const AccMode &am, bool clear) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     ProfScope prof(ctx, RN_K_BP, n, st);
+    float4 *zero = clear ? reinterpret_cast<float4 *>(am.zero) : nullptr;
+    const int zero4 = zero ? (int)(acc_floats(ctx) / 4) : 0;
 #define RN_BP(NCH_)                                                                            \
     hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks_mrf(n)), dim3(RN_RAY_BLOCK), 0, st, \
-                       ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, msgs_out, uniform_acc ? 1 : 0)
+                       ctx->p, n, Sv, vox, rvc, acc_in, msgs_in, msgs_out, am.uniform ? 1 : 0,       \
+                       am.bias, am.biased ? 1 : 0, zero, zero4)
     if (nch <= 2) RN_BP(2);
     else if (nch <= 4) RN_BP(4);
     else if (nch <= 6) RN_BP(6);
@@ -359,7 +403,7 @@ template <bool PACKED, bool CLIP_IN>
 int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
               const float *acc_in, const float *msgs_in, void *acc_out, float *msgs_out,
               hipStream_t st, bool patch_rows = false, bool fixed = false,
-              bool uniform_acc = false) {
+              const AccMode &am = AccMode()) {
     // Patch-ordered rows start with the LDS-box scatter on 128-ray x 32-step tiles.  The
     // kernel counts the chunks whose bounding box did not fit its LDS budget; the count of
     // the previous launches is copied out asynchronously (it may lag a launch) and when too
@@ -386,13 +430,13 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     const size_t M = (size_t)ctx->p.M, VW = PACKED ? 1 : 3;
     const bool split = ctx->overlap == 1 || (ctx->overlap == 2 && level >= 1 && level < LAST);
     const int nA = split && PACKED && n >= 65536 ? (n / 2 + 255) / 256 * 256 : n;
-    launch_bp_kernel<PACKED, CLIP_IN>(ctx, nA, Sv, vox, rvc, acc_in, msgs_in, msgs_out, st, uniform_acc);
+    launch_bp_kernel<PACKED, CLIP_IN>(ctx, nA, Sv, vox, rvc, acc_in, msgs_in, msgs_out, st, am, true);
     RN_LAUNCH_CHECK(ctx);
     if (nA < n) {
         RN_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
         launch_bp_kernel<PACKED, CLIP_IN>(ctx, n - nA, Sv + nA * M, vox + nA * M * VW, rvc + nA, acc_in,
                                           msgs_in ? msgs_in + nA * M : nullptr, msgs_out + nA * M, st,
-                                          uniform_acc);
+                                          am, false);
         RN_LAUNCH_CHECK(ctx);
         RN_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
         launch_scatter_kernel<PACKED>(ctx, nA, msgs_out, vox, rvc, acc_out, ctx->aux, level, fixed);
@@ -418,13 +462,14 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
 template <bool PACKED, bool CLIP_IN>
 int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
                  const float *acc, const float *msgs, const float *cc, float *S_new,
-                 float *depth_map, hipStream_t st, int rays_per_center = 0) {
+                 float *depth_map, hipStream_t st, int rays_per_center = 0,
+                 const AccMode &am = AccMode(), int cc_stride = 4) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     ProfScope prof(ctx, RN_K_DEPTH, n, st);
 #define RN_DE(NCH_)                                                                             \
     hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks_mrf(n)), dim3(RN_RAY_BLOCK), 0, st, \
                        ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, S_new, depth_map,           \
-                       rays_per_center)
+                       rays_per_center, am.bias, am.biased ? 1 : 0, cc_stride)
     if (nch <= 2) RN_DE(2);
     else if (nch <= 4) RN_DE(4);
     else if (nch <= 6) RN_DE(6);
@@ -436,9 +481,10 @@ int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const 
     return RN_OK;
 }
 
-// floats of one resident (bricked) accumulator: every axis padded to a multiple of 4
-inline int64_t acc_floats(const rn_ctx *ctx) {
-    return (int64_t)((ctx->p.gx + 3) / 4) * ctx->p.nby * ctx->p.nbz * 64;
+inline AccMode uniform_mode(bool uniform) {
+    AccMode am;
+    am.uniform = uniform;
+    return am;
 }
 
 int need_axes(rn_ctx *ctx) {
@@ -493,6 +539,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     ctx->box_pin = getenv("RAYNET_HIP_BOX_PIN") != nullptr;
     const char *ov = getenv("RAYNET_HIP_OVERLAP");
     ctx->overlap = ov ? (atoi(ov) != 0 ? 1 : 0) : 2;
+    ctx->generic_sweep = getenv("RAYNET_HIP_GENERIC_SWEEP") != nullptr;
     ctx->prof_mask = ~0u;
     if (sweep_lds(p) > 160 * 1024) {      // before anything is allocated
         delete ctx;
@@ -530,6 +577,30 @@ void rn_destroy(rn_ctx *ctx) {
     delete[] ctx->prof_id;
     delete[] ctx->prof_rays;
     delete ctx;
+}
+
+int rn_get_options(const rn_ctx *ctx, rn_options *out) {
+    if (!ctx || !out) return RN_ERR_INVALID;
+    out->scatter_mode = ctx->scatter_mode;
+    out->box_level = ctx->box_level0;
+    out->box_pin = ctx->box_pin ? 1 : 0;
+    out->overlap = ctx->overlap;
+    out->generic_sweep = ctx->generic_sweep;
+    return RN_OK;
+}
+
+int rn_set_options(rn_ctx *ctx, const rn_options *opt) {
+    if (!ctx || !opt) return RN_ERR_INVALID;
+    if ((opt->scatter_mode != -1 && opt->scatter_mode != 0 && opt->scatter_mode != 2) ||
+        opt->box_level < 0 || opt->box_level > 2 || opt->overlap < 0 || opt->overlap > 2)
+        return fail(ctx, RN_ERR_INVALID, "rn_set_options: value out of range");
+    ctx->scatter_mode = opt->scatter_mode;
+    ctx->box_level = ctx->box_level0 = opt->box_level;
+    ctx->box_pin = opt->box_pin != 0;
+    ctx->overlap = opt->overlap;
+    ctx->generic_sweep = opt->generic_sweep != 0;
+    ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
+    return RN_OK;
 }
 
 int rn_set_voxel_grid(rn_ctx *ctx, const float *voxel_grid, void *stream) {
@@ -955,7 +1026,7 @@ int rn_scene_bp_sweep(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vo
     return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in,
                                   (first_sweep & RN_SWEEP_ZERO_MSGS) ? nullptr : msgs, acc_part,
                                   msgs, S(stream), row_layout == RN_ROWS_PATCHES, false,
-                                  (first_sweep & RN_SWEEP_UNIFORM_ACC) != 0);
+                                  uniform_mode((first_sweep & RN_SWEEP_UNIFORM_ACC) != 0));
 }
 
 int rn_scene_bp_sweep_fixed(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
@@ -968,7 +1039,7 @@ int rn_scene_bp_sweep_fixed(rn_ctx *ctx, int32_t n, const float *Sr, const int32
     return launch_bp<true, false>(ctx, n, Sr, vox, rvc, acc_in,
                                   (first_sweep & RN_SWEEP_ZERO_MSGS) ? nullptr : msgs,
                                   acc_part_fixed, msgs, S(stream), row_layout == RN_ROWS_PATCHES,
-                                  true, (first_sweep & RN_SWEEP_UNIFORM_ACC) != 0);
+                                  true, uniform_mode((first_sweep & RN_SWEEP_UNIFORM_ACC) != 0));
 }
 
 int rn_acc_combine_fixed(rn_ctx *ctx, int64_t *acc_part_fixed, float prior, float *acc_out,
@@ -978,6 +1049,18 @@ int rn_acc_combine_fixed(rn_ctx *ctx, int64_t *acc_part_fixed, float prior, floa
     ProfScope prof(ctx, RN_K_ACC, 0, S(stream));
     hipLaunchKernelGGL(k_acc_combine_fixed, dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream),
                        reinterpret_cast<unsigned long long *>(acc_part_fixed), G, prior, acc_out);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_acc_combine_fixed_range(rn_ctx *ctx, int64_t *acc_part_fixed, int64_t count, float prior,
+                               float *acc_out, void *stream) {
+    if (!ctx || !acc_part_fixed || !acc_out || count < 0)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    if (count == 0) return RN_OK;
+    ProfScope prof(ctx, RN_K_ACC, 0, S(stream));
+    hipLaunchKernelGGL(k_acc_combine_fixed, dim3(fill_blocks(count)), dim3(BLOCK), 0, S(stream),
+                       reinterpret_cast<unsigned long long *>(acc_part_fixed), count, prior, acc_out);
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }
@@ -1025,6 +1108,75 @@ int rn_scene_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
     if (rays_per_center < 0) return fail(ctx, RN_ERR_INVALID, "bad argument");
     return launch_depth<true, false>(ctx, n, Sr, vox, rvc, acc, msgs, camera_center, S_new,
                                      depth_map, S(stream), rays_per_center);
+}
+
+int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t iteration,
+                 int32_t image, void *stream) {
+    if (!ctx || !pl || pl->n_images < 1 || pl->n < 0 || pl->rows_per_image < pl->n ||
+        pl->rows_per_image % 256 || iteration < 0 || image >= pl->n_images ||
+        (!pl->ray_idxs && pl->n) || !pl->features_views || !pl->cameras || !pl->vox || !pl->rvc || !pl->Sr || !pl->msgs ||
+        !pl->acc[0] || !pl->acc[1] || !pl->depth ||
+        (phases & ~(RN_RUN_PREPARE | RN_RUN_SWEEP | RN_RUN_COMBINE | RN_RUN_DEPTH)))
+        return fail(ctx, RN_ERR_INVALID, "rn_scene_run: bad plan or phase");
+    int rc = need_axes(ctx);
+    if (rc) return rc;
+    const bool fixed = pl->acc_fixed != nullptr;
+    const int64_t rows = (int64_t)pl->n_images * pl->rows_per_image;
+    if (rows > 0x7fffffff) return fail(ctx, RN_ERR_INVALID, "rn_scene_run: too many rows");
+    hipStream_t st = S(stream);
+    const int64_t G = acc_floats(ctx);
+    if (phases & RN_RUN_PREPARE) {
+        if (fixed) RN_HIP(ctx, hipMemsetAsync(pl->acc_fixed, 0, sizeof(int64_t) * G, st));
+        if (pl->n > 0)
+        rc = rn_scene_prepare_all(ctx, pl->n_images, pl->n, pl->rows_per_image, pl->ray_idxs,
+                                  pl->features_views, pl->cameras, pl->order, pl->vox, pl->rvc,
+                                  pl->Sr, pl->ray_segments, stream);
+        if (rc) return rc;
+    }
+    if (pl->n == 0) {
+        // a rank without rays (tiny images, many ranks) still takes part in the exchange: its
+        // partial sums are all zero
+        if ((phases & RN_RUN_SWEEP) && !fixed)
+            RN_HIP(ctx, hipMemsetAsync(pl->acc[iteration & 1], 0, sizeof(float) * G, st));
+        if ((phases & RN_RUN_COMBINE) && fixed)
+            return rn_acc_combine_fixed(ctx, pl->acc_fixed, pl->prior, pl->acc[iteration & 1], stream);
+        return RN_OK;
+    }
+    if (phases & RN_RUN_SWEEP) {
+        AccMode am;
+        am.uniform = iteration == 0;        // the prior everywhere, no messages yet
+        am.biased = !fixed || iteration == 0;
+        am.bias = pl->prior;
+        am.zero = fixed ? nullptr : pl->acc[iteration & 1];
+        rc = launch_bp<true, false>(ctx, (int)rows, pl->Sr, pl->vox, pl->rvc,
+                                    pl->acc[(iteration + 1) & 1], iteration == 0 ? nullptr : pl->msgs,
+                                    fixed ? (void *)pl->acc_fixed : (void *)pl->acc[iteration & 1],
+                                    pl->msgs, st, pl->row_layout == RN_ROWS_PATCHES, fixed, am);
+        if (rc) return rc;
+    }
+    if ((phases & RN_RUN_COMBINE) && fixed) {
+        rc = rn_acc_combine_fixed(ctx, pl->acc_fixed, pl->prior, pl->acc[iteration & 1], stream);
+        if (rc) return rc;
+    }
+    if (phases & RN_RUN_DEPTH) {
+        AccMode am;
+        am.biased = !fixed;
+        am.bias = pl->prior;
+        const float *acc = pl->acc[(iteration + 1) & 1];
+        const int cam_stride = 12 * ctx->p.N + 12 + 4;
+        const float *cc = pl->cameras + 12 * ctx->p.N + 12;
+        const size_t M = (size_t)ctx->p.M;
+        if (image < 0)
+            return launch_depth<true, false>(ctx, (int)rows, pl->Sr, pl->vox, pl->rvc, acc, pl->msgs,
+                                             cc, nullptr, pl->depth, st, (int)pl->rows_per_image,
+                                             am, cam_stride);
+        const size_t row0 = (size_t)image * pl->rows_per_image;
+        return launch_depth<true, false>(ctx, pl->n, pl->Sr + row0 * M, pl->vox + row0 * M,
+                                         pl->rvc + row0, acc, pl->msgs + row0 * M,
+                                         cc + (size_t)image * cam_stride, nullptr, pl->depth + row0,
+                                         st, 0, am);
+    }
+    return RN_OK;
 }
 
 int rn_prof_begin(rn_ctx *ctx, int32_t capacity) {

@@ -159,21 +159,26 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
                                        const float *__restrict__ S,
                                        const int32_t *__restrict__ vox,
                                        const float *__restrict__ acc_in, const float *msgs_in,
-                                       float *msgs_out, bool uniform_acc) {
+                                       float *msgs_out, bool uniform_acc, float acc_bias,
+                                       bool biased) {
     RayRows<NB> cur;
     load_rows<NB, PACKED, RN_BP_NT>(p, cur, S, vox, msgs_in, r, count, lane);
     // accumulator gather (depends on the voxel rows).  uniform_acc: every voxel holds
     // acc_in[0] (the first iteration starts from the prior everywhere) -- nothing to gather,
     // and with zero messages on top the occupancy is one constant for the whole sweep.
     float av[NB];
-    const float a0 = uniform_acc ? acc_in[0] : 0.0f;
+    const float a0 = uniform_acc ? (biased ? acc_bias : acc_in[0]) : 0.0f;
 #pragma unroll
     for (int ch = 0; ch < NB; ch++) {
         const int i = ch * WAVE + lane;
         av[ch] = a0;
 #ifndef RN_EXP_BP_NOGATHER      // timing experiments only (wrong results), as the ones below
-        if (!uniform_acc && ch * WAVE < count && i < count)
+        if (!uniform_acc && ch * WAVE < count && i < count) {
             av[ch] = gather_acc(acc_in, lin_of<PACKED>(p, cur.pk[ch]));
+            // acc_in holds the messages' SUM only and the prior is added here (the same
+            // `prior + sum` rn_acc_combine stores, without that kernel and its 3 G floats)
+            if (biased) av[ch] = acc_bias + av[ch];
+        }
 #else
         av[ch] = __builtin_bit_cast(float, cur.pk[ch]) * 1e-30f;
 #endif
@@ -274,15 +279,27 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_bp(Params p, int n, const floa
                                               const int32_t *__restrict__ rvc,
                                               const float *__restrict__ acc_in,
                                               const float *msgs_in, float *msgs_out,
-                                              int uniform_acc) {
+                                              int uniform_acc, float acc_bias, int biased,
+                                              float4 *zero_buf, int zero_count4) {
     int lane;
-    const int r = ray_of_wave<RN_RAY_BLOCK>(n, lane);
+    // zero_buf: the partial accumulator the NEXT scatter adds into (nobody reads it during this
+    // launch) is cleared here, a float4 per lane of the first wavefronts, instead of by a
+    // kernel of its own between the sweeps
+    if (zero_buf) {
+        constexpr int WPB = RN_RAY_BLOCK / WAVE;
+        const int nw = (n + WPB - 1) / WPB * WPB;
+        const int w = blockIdx.x * WPB + (int)(threadIdx.x >> 6);
+        for (int i = w * WAVE + (int)(threadIdx.x & (WAVE - 1)); i < zero_count4; i += nw * WAVE)
+            zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int r = ray_of_wave<RN_RAY_BLOCK, RN_XCD_CHUNK_BP>(n, lane);
     if (r < 0) return;
     const int count = min(uniform(rvc[r]), p.M);
     if (count <= 1) return;   // mrf_np.py:300: such rays send nothing
     const int nch = (count + WAVE - 1) / WAVE;
 #define RN_BP_BODY(NB) \
-    bp_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc_in, msgs_in, msgs_out, uniform_acc != 0)
+    bp_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc_in, msgs_in, msgs_out, uniform_acc != 0, \
+                                acc_bias, biased != 0)
     RN_DISPATCH_CHUNKS(NCH, nch, RN_BP_BODY);
 #undef RN_BP_BODY
 }
@@ -571,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
     __shared__ int red_cnt[WAVES_PER_BLOCK];
     __shared__ int cnts[BOX_RAYS];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
-    const int r0 = xcd_block(blockIdx.x, gridDim.x) * BOX_RAYS;
+    const int r0 = xcd_block<RN_XCD_CHUNK_SCATTER>(blockIdx.x, gridDim.x) * BOX_RAYS;
     // a wavefront instruction covers RPI rays x BOX_STEPS steps; thread (sub, col) of wave w
     // owns step col of the rays w*RPI + sub + k*STRIDE
     constexpr int RPI = WAVE / BOX_STEPS;
@@ -880,7 +897,7 @@ __device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int
                                           const int32_t *__restrict__ vox,
                                           const float *__restrict__ acc,
                                           const float *__restrict__ msgs, float *S_new, float &best,
-                                          int &best_i) {
+                                          int &best_i, float acc_bias, bool biased) {
     RayRows<NB> cur;
     load_rows<NB, PACKED>(p, cur, S, vox, msgs, r, count, lane);
     float av[NB];
@@ -888,7 +905,10 @@ __device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int
     for (int ch = 0; ch < NB; ch++) {
         const int i = ch * WAVE + lane;
         av[ch] = 0.0f;
-        if (ch * WAVE < count && i < count) av[ch] = gather_acc(acc, lin_of<PACKED>(p, cur.pk[ch]));
+        if (ch * WAVE < count && i < count) {
+            av[ch] = gather_acc(acc, lin_of<PACKED>(p, cur.pk[ch]));
+            if (biased) av[ch] = acc_bias + av[ch];      // see bp_ray
+        }
     }
     clip_renorm_rows<NB, CLIP_IN>(cur.sv, count, lane);
     float wv[NB];
@@ -930,18 +950,20 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const f
                                                  const float *__restrict__ msgs,
                                                  const float *__restrict__ axes,
                                                  const float *__restrict__ cc, float *S_new,
-                                                 float *depth_map, int rays_per_center) {
+                                                 float *depth_map, int rays_per_center,
+                                                 float acc_bias, int biased, int cc_stride) {
     int lane;
-    const int r = ray_of_wave<RN_RAY_BLOCK>(n, lane);
+    const int r = ray_of_wave<RN_RAY_BLOCK, RN_XCD_CHUNK_DEPTH>(n, lane);
     if (r < 0) return;
-    if (rays_per_center > 0 && cc) cc += 4 * (r / rays_per_center);
+    if (rays_per_center > 0 && cc) cc += (size_t)cc_stride * (r / rays_per_center);
     const int count = min(uniform(rvc[r]), p.M);
     float best = -INFINITY;
     int best_i = 0;
     if (count > 1) {
         const int nch = (count + WAVE - 1) / WAVE;
 #define RN_DE_BODY(NB) \
-    depth_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc, msgs, S_new, best, best_i)
+    depth_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc, msgs, S_new, best, best_i, acc_bias, \
+                                   biased != 0)
         RN_DISPATCH_CHUNKS(NCH, nch, RN_DE_BODY);
 #undef RN_DE_BODY
     } else if (S_new) {

@@ -317,7 +317,7 @@ void k_sweep_map(
         __syncthreads();
     }
     int lane;
-    int r = ray_of_wave(n, lane);
+    int r = ray_of_wave<BLOCK, RN_XCD_CHUNK_SWEEP>(n, lane);
     if (r < 0) return;
     RN_PHASE_DECL;
     RN_PHASE_MARK(0);                      // (clock read only)

@@ -30,17 +30,31 @@ sharded contiguously over the ranks; each rank scatters into its own zeroed
 accumulator and one all-reduce (RCCL) per BP iteration merges them before the
 prior is added once.
 """
-import os
-
 import numpy as np
 import torch
 
+from . import _lib
 from .hip_implementations import get_context
+from .hip_implementations.options import PathOptions, shard_alpha_for
 from .hip_implementations.mvcnn_with_ray_marching_and_voxels_mapping import \
     batch_mvcnn_voxel_traversal_with_ray_marching_with_depth_estimation
 from .hip_implementations.raynet_fp import perform_raynet_fp
 from .hip_implementations.similarities import \
     perform_multi_view_cnn_forward_pass_with_depth_estimation
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev):
+    """(exchange / stitch stream, copy stream) of a device, created ONCE per process: HIP maps
+    streams onto a handful of hardware queues in creation order, and a side stream that lands on
+    the main stream's queue serialises with it (measured: every second driver object of a
+    process, each creating its own pair, ran 0.25 ms per step slower)."""
+    key = (dev.type, dev.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _SIDE_STREAMS[key]
 
 
 def _dist():
@@ -272,7 +286,7 @@ class RayNetForwardPass(ForwardPass):
 
     def __init__(self, model, generation_params, sampling_scheme, image_shape, rays_batch,
                  filter_out_rays=False, bp_iterations=3, schedule="resident",
-                 reference_quirks=False, backend_factory=None, deterministic=False):
+                 reference_quirks=False, backend_factory=None, deterministic=None, options=None):
         super(RayNetForwardPass, self).__init__(model, generation_params, sampling_scheme,
                                                 image_shape, rays_batch, filter_out_rays)
         assert schedule in ("resident", "reference")
@@ -284,40 +298,54 @@ class RayNetForwardPass(ForwardPass):
         # world_size-2 gloo test injects a host stand-in to exercise the sharding and
         # all-reduce logic without a GPU.)
         self._backend_factory = backend_factory
-        # deterministic=True: messages are summed as 64-bit fixed-point integers (scatter,
-        # accumulator and the all-reduce across ranks): the accumulator and everything after
-        # it are bit-identical from run to run and for any number of GPUs (SURVEY.md 8e)
-        self.deterministic = deterministic or os.environ.get("RAYNET_DETERMINISTIC", "0") == "1"
-        # schedule knob only; results do not depend on it (RAYNET_SWEEP_REORDER=0 for A/B runs)
-        self.sweep_reorder = os.environ.get("RAYNET_SWEEP_REORDER", "1") != "0"
-        # row layout of the resident buffers: 16x16 pixel patches (RAYNET_RAY_TILE=0: ray-index
-        # order, AxB: other patch shapes; A/B knob, results do not depend on it)
-        tile = os.environ.get("RAYNET_RAY_TILE", "16x16")
-        self.ray_tile = tuple(int(t) for t in tile.split("x")) if "x" in tile else None
+        # every schedule / A-B knob lives in ONE PathOptions (hip_implementations/options.py);
+        # the environment only overrides its defaults, read there.  `deterministic=True`
+        # (messages summed as 64-bit fixed-point integers in the scatter, the accumulator and the
+        # all-reduce: the same bits from run to run and for any number of GPUs, SURVEY.md 8e)
+        # is the one option with a constructor argument of its own.
+        self.options = options if options is not None else PathOptions.from_env()
+        if deterministic is not None:
+            self.options = self.options.replace(deterministic=bool(deterministic))
         self._plan = None          # see _build_plan
         self.shard_balance = None  # per image: traversed voxels of every rank's shard (world > 1)
-        self._side_stream = None
+        self.shard_alpha = None    # ... and the per-ray constant the cuts weighed rays with
+        self._side_stream = self._copy_stream = None
         self.ref_idx = -1
         self._ctx = None
         self._de = None
         self.timings = {}
         # state kept for inspection by tests / tools
         self._acc_flat = self._acc_grid = None
+        self._acc_bias = 0.0
         self.messages = _Messages()   # per image: [rows, M] messages of this rank's rays
         self.voxel_count = {}
         self.ray_index = {}      # per image: ray index (pixel x*H + y) of every row
 
+    # the options tests and tools flip on an existing object
+    ray_tile = property(lambda self: self.options.ray_tile,
+                        lambda self, v: setattr(self, "options", self.options.replace(ray_tile=v)))
+    deterministic = property(lambda self: self.options.deterministic,
+                             lambda self, v: setattr(self, "options",
+                                                     self.options.replace(deterministic=bool(v))))
+    sweep_reorder = property(lambda self: self.options.sweep_reorder,
+                             lambda self, v: setattr(self, "options",
+                                                     self.options.replace(sweep_reorder=bool(v))))
+
     @property
     def accumulator(self):
         """[gx][gy][gz] log-odds accumulator of the last pass (mrf_bp.cu:3-10 layout).  The
-        resident pass keeps it bricked; the regrid happens when somebody asks."""
+        resident pass keeps it bricked -- and, on the plan path, as the sum of the messages
+        without the prior; the regrid (and `prior + sum`) happens when somebody asks."""
         if self._acc_grid is None and self._acc_flat is not None:
-            self._acc_grid = self._ctx.acc_to_grid(self._acc_flat)
+            grid = self._ctx.acc_to_grid(self._acc_flat)
+            if self._acc_bias != 0.0:
+                grid = grid.add_(self._acc_bias)      # prior + sum, the value a sweep reads
+            self._acc_grid = grid
         return self._acc_grid
 
     @accumulator.setter
     def accumulator(self, value):
-        self._acc_grid, self._acc_flat = value, None
+        self._acc_grid, self._acc_flat, self._acc_bias = value, None, 0.0
 
     # -- helpers -----------------------------------------------------------
     def _context(self, scene, F):
@@ -338,6 +366,8 @@ class RayNetForwardPass(ForwardPass):
                 scene.voxel_grid(gp.grid_shape).transpose(1, 2, 3, 0)))   # forward_pass.py:573-575
             self._ctx.set_voxel_grid(self._vg)
             self._ctx._grid_src = self._vg
+        if hasattr(self._ctx, "set_options"):
+            self._ctx.set_options(self.options)     # contexts are shared per configuration
         return self._ctx
 
     def _view_features(self, scene, ref_idxs):
@@ -370,32 +400,180 @@ class RayNetForwardPass(ForwardPass):
             return self._forward_pass_reference(scene, images_range)
         return self._forward_pass_resident(scene, images_range)
 
-    # -- the resident schedule ------------------------------------------------
+    # -- the plan of a resident pass -------------------------------------------
+    # Everything of a pass that depends on the scene's cameras, the image range, the options and
+    # the sharding only -- camera table, feature-pointer table, ray lists, the ranks' shard
+    # bounds, the HBM buffers, the C plan, the host buffers the maps land in -- is built once
+    # and reused while those stay the same (0.2 ms of host work per pass otherwise; 10 % of a
+    # rank's step at 8 GPUs).  Three steps: lists, cuts, buffers.
+    def _plan_lists(self, scene, refs, views_of, ctx):
+        """The images' ray lists in ROW order (what row i of an image's buffers holds)."""
+        H, W = scene.image_shape
+        opt, dev = self.options, ctx.device
+        patch_rows = opt.ray_tile is not None
+        # patches are enumerated along the direction of the neighbour views' epipolar lines (of
+        # the first reference image: one list serves the whole scene)
+        epipolar_rows = bool(refs) and sweep_direction(
+            H, W, [scene.get_image(v) for v in views_of[refs[0]]]) == "rows"
+        along_rows = patch_rows and bool(refs) and (
+            opt.tile_along == "rows" or (opt.tile_along == "auto" and epipolar_rows))
+        lists, shared = {}, None
+        for r in refs:
+            if self._filter_out_rays:
+                rays = ctx.dev(np.ascontiguousarray(
+                    self.get_valid_rays_per_image(scene, r).astype(np.int32)))
+                if patch_rows:
+                    rays = tile_order(rays, H, W, *opt.ray_tile, along_rows=along_rows)
+            else:       # all H*W rays (forward_pass.py:166-168): built on the device, once
+                if shared is None:
+                    shared = torch.arange(H * W, dtype=torch.int32, device=dev)
+                    if patch_rows:
+                        shared = tile_order(shared, H, W, *opt.ray_tile, along_rows=along_rows)
+                rays = shared
+            lists[r] = rays
+        return lists, shared
+
+    def _plan_cuts(self, ctx, dist, refs, lists, shared, cam_dev, world):
+        """bounds[k][q] .. bounds[k][q+1] = rows of image k owned by rank q, and (world > 1,
+        work-balanced shards) every rank's traversed voxels per image."""
+        gp, opt = self._generation_params, self.options
+        V = len(refs)
+        bounds = [[shard_bounds(len(lists[r]), q, world)[0] for q in range(world)] +
+                  [len(lists[r])] for r in refs]
+        if not (world > 1 and V > 0 and opt.shard == "voxels" and hasattr(ctx, "count_voxels")):
+            return bounds, None
+        # equal RAY counts leave the ranks unequal work: the border strips of an image miss
+        # most of the box (config 2: the strips' voxel totals spread 0.1 .. 1.6 x the mean).
+        # The traversal's counts (bit-exact integers, the same on every rank: no exchange)
+        # weigh every ray as `count + alpha * mean count`, alpha = the plane sweep's per-ray
+        # cost in units of the mean ray's per-voxel work (options.shard_alpha_for: from the
+        # shape, or PathOptions.shard_alpha); cuts fall on whole 256-row scatter tiles.
+        # Images that share one ray list get the SAME cuts (their traversal / sweep is one
+        # launch over all of them, and so is every later kernel: only a rank's total
+        # counts), from the weights summed over the images.
+        N, D = gp.neighbors + 1, gp.depth_planes
+
+        def cut(c, images):
+            """c: int64 [n] voxel counts per row (summed over `images` images) -> world + 1
+            row bounds of equal weight"""
+            n_k = int(c.numel())
+            if n_k == 0:
+                return [0] * (world + 1)
+            total = int(c.sum().item())
+            alpha = opt.shard_alpha if opt.shard_alpha is not None else \
+                shard_alpha_for(N, D, total / float(n_k * images))
+            self.shard_alpha = alpha
+            # integer weights: their prefix sums are exact whatever the scan order, so
+            # every rank computes the same cuts from the same (bit-exact) counts
+            extra = int(round(16 * alpha * total / n_k))
+            w = torch.cumsum(c * 16 + extra, 0)
+            total_w = int(w[-1].item())
+            targets = torch.tensor([total_w * q // world for q in range(1, world)],
+                                   dtype=torch.int64, device=w.device)
+            b = torch.searchsorted(w, targets).cpu().tolist()
+            # whole 256-row scatter tiles where the image is large enough for that to
+            # leave the balance intact, finer otherwise
+            align = 256
+            while align > 1 and align * 4 * world > n_k:
+                align //= 2
+            cuts = [0]
+            for v in b:
+                cuts.append(max(cuts[-1], min(n_k, (int(v) + align // 2) // align * align)))
+            return cuts + [n_k]
+
+        def shares(c, cuts):
+            cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=c.device),
+                            torch.cumsum(c, 0)]).cpu()
+            return [int(cs[cuts[q + 1]] - cs[cuts[q]]) for q in range(world)]
+
+        if shared is not None:
+            counts = ctx.count_voxels(shared, cam_dev).to(torch.int64)      # [V, n]
+            cuts = cut(counts.sum(0), V)
+            bounds = [cuts for _ in refs]
+            balance = [shares(counts[k], cuts) for k in range(V)]
+        else:
+            bounds, balance = [], []
+            for k, r in enumerate(refs):
+                c = ctx.count_voxels(lists[r], cam_dev[k:k + 1])[0].to(torch.int64)
+                bounds.append(cut(c, 1))
+                balance.append(shares(c, bounds[-1]))
+        if dist is not None:         # belt and braces: the ranks must agree on the cuts
+            t = torch.tensor(bounds, dtype=torch.int64, device=ctx.device)
+            lo_t, hi_t = t.clone(), t.clone()
+            dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo_t, hi_t), "ranks disagree on the shard bounds"
+        return bounds, balance
+
+    def _plan_buffers(self, ctx, plan, refs, old_bytes):
+        """HBM: messages and counts of ALL images stay resident (they carry state across the
+        iterations); the voxel lists and columns of as many images as fit -- the rest are
+        recomputed group by group in every sweep, like the reference recomputes everything."""
+        gp, opt, dev = self._generation_params, self.options, ctx.device
+        M, V, npad = gp.max_number_of_marched_voxels, len(refs), plan["npad"]
+        G = ctx.acc_size()
+        per_image = npad * M * 4
+        budget = float(opt.resident_gb) * 2 ** 30
+        if budget <= 0 and dev.type == "cuda":
+            free, _ = torch.cuda.mem_get_info(dev)
+            # what the caching allocator holds but nobody uses is ours to take as well, and so
+            # are the outgoing plan's buffers (released below, before anything is allocated)
+            free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev) + old_bytes
+            budget = 0.9 * free
+        fixed = V * per_image + 4 * G * 8 + V * npad * 48
+        if budget > 0 and fixed + 2 * per_image > budget:
+            raise MemoryError(
+                "resident schedule: the messages of %d reference images (%.1f GB) do not leave "
+                "room for one image's columns in %.1f GB of HBM; run fewer images per call"
+                % (V, V * per_image / 2 ** 30, budget / 2 ** 30))
+        Vg = V if budget <= 0 else int(max(1, min(V, (budget - fixed) // (2 * per_image))))
+        if Vg < V:
+            import warnings
+            warnings.warn("resident schedule: the columns of %d of %d reference images fit the HBM "
+                          "budget (%.1f GB); traversal and plane sweep are recomputed group by "
+                          "group in every sweep" % (Vg, V, budget / 2 ** 30))
+        rows_g = Vg * npad
+        fixed_pt = opt.deterministic and hasattr(ctx, "scene_bp_sweep_fixed")
+        prior = plan["prior"]
+        plan.update(
+            groups=[list(range(g, min(g + Vg, V))) for g in range(0, V, Vg)] if V else [], Vg=Vg,
+            fixed=fixed_pt, bytes=fixed + 2 * rows_g * M * 4,
+            vox=torch.empty((rows_g, M), dtype=torch.int32, device=dev),
+            Sr=torch.empty((rows_g, M), dtype=torch.float32, device=dev),
+            msgs=torch.empty((V * npad, M), dtype=torch.float32, device=dev),   # see _Messages
+            rvc=torch.zeros((V * npad,), dtype=torch.int32, device=dev),   # padding rays: count 0
+            depth=torch.zeros((V * npad,), dtype=torch.float32, device=dev),
+            # granular path: iteration 0 reads the prior from a buffer no sweep ever writes
+            acc_prior=torch.full((G,), prior, dtype=torch.float32, device=dev),
+            acc_a=torch.empty((G,), dtype=torch.float32, device=dev),
+            acc_b=torch.empty((G,), dtype=torch.float32, device=dev),
+            acc_part=(torch.zeros((G,), dtype=torch.int64, device=dev) if fixed_pt else
+                      torch.zeros((ctx.acc_copies(), G), dtype=torch.float32, device=dev)))
+
     def _build_plan(self, scene, refs, bank, ctx, dist, rank, world):
-        """Everything of a resident pass that depends on the scene's cameras, the image range
-        and the sharding only -- camera table, feature-pointer table, ray lists, the ranks'
-        shard bounds, the HBM buffers -- built once and reused while those stay the same
-        (0.2 ms of host work per pass otherwise; 10 % of a rank's step at 8 GPUs)."""
-        gp = self._generation_params
-        M = gp.max_number_of_marched_voxels
+        gp, opt = self._generation_params, self.options
+        M, N = gp.max_number_of_marched_voxels, gp.neighbors + 1
         H, W = scene.image_shape
         dev = ctx.device
-        N = gp.neighbors + 1
         V = len(refs)
-        stride = 12 * N + 12 + 4
-        views_of = {r: scene.view_indices_with_neighbors(r, gp.neighbors) for r in refs}
+        views_of = {r: tuple(scene.view_indices_with_neighbors(r, gp.neighbors)) for r in refs}
         ptrs = tuple(tuple(bank[v].data_ptr() for v in views_of[r]) for r in refs)
-        patch_rows = self.ray_tile is not None
-        # the plan of a scene OBJECT is reused as long as the object lives (its cameras are
-        # immutable: K, R, t are constructor arguments, common/camera.py), the feature maps
-        # sit where they sat and nothing that shapes the plan changed
-        key = (id(scene), ptrs, tuple(refs), H, W, M, N, world, rank, self.ray_tile,
-               self.sweep_reorder, self.rays_batch, self.deterministic, str(dev),
-               os.environ.get("RAYNET_TILE_ALONG", "auto"), os.environ.get("RAYNET_SHARD", "voxels"),
-               os.environ.get("RAYNET_RESIDENT_GB", "0"))
+        cams = tuple(scene.get_image(v).camera for r in refs for v in views_of[r])
+        # geometry: the cameras (objects whose P / P_pinv / center are computed once and cached,
+        # common/camera.py -- a changed camera is a new object; the plan holds them, so an id is
+        # never recycled), the neighbour selection, the image range, the shapes, the options and
+        # the sharding.  The feature maps' ADDRESSES are not geometry: when only they moved
+        # (the allocator placed recomputed maps elsewhere) the pointer table is refreshed.
+        key = (id(scene), tuple(id(c) for c in cams), tuple(sorted(views_of.items())), tuple(refs),
+               H, W, M, N, gp.depth_planes, world, rank, opt.key(), self.rays_batch, str(dev),
+               self._prior())
         plan = self._plan
         if plan is not None and plan["key"] == key and not self._filter_out_rays:
+            if plan["ptrs"] != ptrs:
+                plan["table"].copy_(torch.tensor(ptrs, dtype=torch.int64))
+                plan["ptrs"] = ptrs
             return plan
+        stride = 12 * N + 12 + 4
         cam_host = np.zeros((V, stride), dtype=np.float32)
         for k, r in enumerate(refs):
             P, P_inv, center = self._camera_arrays([scene.get_image(v) for v in views_of[r]])
@@ -407,91 +585,9 @@ class RayNetForwardPass(ForwardPass):
         cam_dev = ctx.dev(cam_host)
         if hasattr(ctx, "scatter_reset"):
             ctx.scatter_reset()          # new cameras: the scatter re-learns its tile shape
-        # patches are enumerated along the direction of the neighbour views' epipolar lines (of
-        # the first reference image: one list serves the whole scene)
-        epipolar_rows = V > 0 and sweep_direction(
-            H, W, [scene.get_image(v) for v in views_of[refs[0]]]) == "rows"
-        along = os.environ.get("RAYNET_TILE_ALONG", "auto")
-        along_rows = patch_rows and V > 0 and (along == "rows" or (along == "auto" and epipolar_rows))
-
-        # ---- the images' ray lists in ROW order (what row i of an image's buffers holds)
-        lists = {}
-        shared = None
-        for k, r in enumerate(refs):
-            if self._filter_out_rays:
-                rays = ctx.dev(np.ascontiguousarray(
-                    self.get_valid_rays_per_image(scene, r).astype(np.int32)))
-                if patch_rows:
-                    rays = tile_order(rays, H, W, *self.ray_tile, along_rows=along_rows)
-            else:       # all H*W rays (forward_pass.py:166-168): built on the device, once
-                if shared is None:
-                    shared = torch.arange(H * W, dtype=torch.int32, device=dev)
-                    if patch_rows:
-                        shared = tile_order(shared, H, W, *self.ray_tile, along_rows=along_rows)
-                rays = shared
-            lists[r] = rays
-
-        # ---- shard bounds: bounds[k][q] .. bounds[k][q+1] = rows of image k owned by rank q
-        bounds = [[shard_bounds(len(lists[r]), q, world)[0] for q in range(world)] +
-                  [len(lists[r])] for r in refs]
-        balance = None
-        if world > 1 and V > 0 and os.environ.get("RAYNET_SHARD", "voxels") == "voxels" and \
-                hasattr(ctx, "count_voxels"):
-            # equal RAY counts leave the ranks unequal work: the border strips of an image miss
-            # most of the box (config 2: the strips' voxel totals spread 0.1 .. 1.6 x the mean).
-            # The traversal's counts (bit-exact integers, the same on every rank: no exchange)
-            # weigh every ray as `count + alpha`, alpha = the plane sweep's per-ray cost in
-            # voxel units; cuts fall on whole 256-row scatter tiles.
-            # Images that share one ray list get the SAME cuts (their traversal / sweep is one
-            # launch over all of them, and so is every later kernel: only a rank's total
-            # counts), from the weights summed over the images.
-            alpha = float(os.environ.get("RAYNET_SHARD_ALPHA", "0.6"))
-
-            def cut(c):
-                """c: int64 [n] voxel counts per row -> world + 1 row bounds of equal weight"""
-                n_k = int(c.numel())
-                if n_k == 0:
-                    return [0] * (world + 1)
-                # integer weights: their prefix sums are exact whatever the scan order, so
-                # every rank computes the same cuts from the same (bit-exact) counts
-                extra = int(round(16 * alpha * int(c.sum().item()) / n_k))
-                w = torch.cumsum(c * 16 + extra, 0)
-                total_w = int(w[-1].item())
-                targets = torch.tensor([total_w * q // world for q in range(1, world)],
-                                       dtype=torch.int64, device=w.device)
-                b = torch.searchsorted(w, targets).cpu().tolist()
-                # whole 256-row scatter tiles where the image is large enough for that to
-                # leave the balance intact, finer otherwise
-                align = 256
-                while align > 1 and align * 4 * world > n_k:
-                    align //= 2
-                cuts = [0]
-                for v in b:
-                    cuts.append(max(cuts[-1], min(n_k, (int(v) + align // 2) // align * align)))
-                return cuts + [n_k]
-
-            def shares(c, cuts):
-                cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=c.device),
-                                torch.cumsum(c, 0)]).cpu()
-                return [int(cs[cuts[q + 1]] - cs[cuts[q]]) for q in range(world)]
-
-            if shared is not None:
-                counts = ctx.count_voxels(shared, cam_dev).to(torch.int64)      # [V, n]
-                cuts = cut(counts.sum(0))
-                bounds = [cuts for _ in refs]
-                balance = [shares(counts[k], cuts) for k in range(V)]
-            else:
-                bounds, balance = [], []
-                for k, r in enumerate(refs):
-                    c = ctx.count_voxels(lists[r], cam_dev[k:k + 1])[0].to(torch.int64)
-                    bounds.append(cut(c))
-                    balance.append(shares(c, bounds[-1]))
-            if dist is not None:         # belt and braces: the ranks must agree on the cuts
-                t = torch.tensor(bounds, dtype=torch.int64, device=dev)
-                lo_t, hi_t = t.clone(), t.clone()
-                dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
-                dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
-                assert torch.equal(lo_t, hi_t), "ranks disagree on the shard bounds"
+        patch_rows = opt.ray_tile is not None
+        lists, shared = self._plan_lists(scene, refs, views_of, ctx)
+        bounds, balance = self._plan_cuts(ctx, dist, refs, lists, shared, cam_dev, world)
         shards = []
         for k, r in enumerate(refs):
             lo, hi = bounds[k][rank], bounds[k][rank + 1]
@@ -501,49 +597,19 @@ class RayNetForwardPass(ForwardPass):
         npad = max([bounds[k][q + 1] - bounds[k][q] for k in range(V) for q in range(world)] + [1])
         npad = (npad + 255) // 256 * 256            # scatter tiles never straddle two images
 
-        # ---- HBM: messages and counts of ALL images stay resident (they carry state across
-        # the iterations); the voxel lists and columns of as many images as fit -- the rest are
-        # recomputed group by group in every sweep, like the reference recomputes everything
-        G = ctx.acc_size()
-        per_image = npad * M * 4
-        budget = float(os.environ.get("RAYNET_RESIDENT_GB", "0")) * 2 ** 30
-        if budget <= 0 and dev.type == "cuda":
-            free, _ = torch.cuda.mem_get_info(dev)
-            if plan is not None:                     # the outgoing plan's buffers are reusable
-                free += plan["bytes"]
-            budget = 0.9 * free
-        fixed = V * per_image + 4 * G * 8 + V * npad * 48
-        if budget > 0 and fixed + 2 * per_image > budget:
-            raise MemoryError(
-                "resident schedule: the messages of %d reference images (%.1f GB) do not leave "
-                "room for one image's columns in %.1f GB of HBM; run fewer images per call"
-                % (V, V * per_image / 2 ** 30, budget / 2 ** 30))
-        Vg = V if budget <= 0 else int(max(1, min(V, (budget - fixed) // (2 * per_image))))
-        groups = [list(range(g, min(g + Vg, V))) for g in range(0, V, Vg)] if V else []
+        old_bytes = plan["bytes"] if plan is not None else 0
+        if self._side_stream is not None:           # nobody reads the outgoing buffers any more
+            torch.cuda.current_stream(dev).wait_stream(self._side_stream)
+            torch.cuda.current_stream(dev).wait_stream(self._copy_stream)
         self._plan = plan = None                     # release the old buffers first
         if hasattr(ctx, "bind_slab_boxes"):
             ctx.bind_slab_boxes(None)                # (the binding holds the old list buffer)
-        rows_g = Vg * npad
-        fixed_pt = self.deterministic and hasattr(ctx, "scene_bp_sweep_fixed")
-        prior = self._prior()
-        plan = dict(
-            key=key, scene=scene, prior=prior, dirty=False,
-            cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
-            balance=balance, shards=shards, npad=npad, groups=groups, Vg=Vg, shared=shared,
-            patch_rows=patch_rows, fixed=fixed_pt,
-            table=torch.tensor(ptrs, dtype=torch.int64).to(dev) if V else None,
-            vox=torch.empty((rows_g, M), dtype=torch.int32, device=dev),
-            Sr=torch.empty((rows_g, M), dtype=torch.float32, device=dev),
-            msgs=torch.empty((V * npad, M), dtype=torch.float32, device=dev),   # see _Messages
-            rvc=torch.zeros((V * npad,), dtype=torch.int32, device=dev),   # padding rays: count 0
-            depth=torch.zeros((V * npad,), dtype=torch.float32, device=dev),
-            # iteration 0 reads the prior from a buffer no sweep ever writes (no refill per pass)
-            acc_prior=torch.full((G,), prior, dtype=torch.float32, device=dev),
-            acc_a=torch.empty((G,), dtype=torch.float32, device=dev),
-            acc_b=torch.empty((G,), dtype=torch.float32, device=dev),
-            acc_part=(torch.zeros((G,), dtype=torch.int64, device=dev) if fixed_pt else
-                      torch.zeros((ctx.acc_copies(), G), dtype=torch.float32, device=dev)),
-            bytes=fixed + 2 * rows_g * M * 4, orders={}, stitch=None)
+        plan = dict(key=key, ptrs=ptrs, scene=scene, cams=cams, prior=self._prior(), dirty=False,
+                    cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
+                    balance=balance, shards=shards, npad=npad, shared=shared,
+                    patch_rows=patch_rows, orders={}, stitch=None, fast=None, slot=0,
+                    table=torch.tensor(ptrs, dtype=torch.int64).to(dev) if V else None)
+        self._plan_buffers(ctx, plan, refs, old_bytes)
         # static views of every image's rows in the scene-wide buffers
         per_image = {}
         for k, r in enumerate(refs):
@@ -554,13 +620,160 @@ class RayNetForwardPass(ForwardPass):
                                 rvc=plan["rvc"][row0:row0 + n], msgs=plan["msgs"][row0:row0 + n],
                                 depth=plan["depth"][row0:row0 + n])
         plan["per_image"] = per_image
-        if hasattr(ctx, "bind_slab_boxes") and plan["vox"].numel() >= M and \
-                os.environ.get("RAYNET_SLAB_BOXES", "1") != "0":
-            ctx.bind_slab_boxes(plan["vox"])      # the scatters merge boxes the traversal left
+        plan["slab_table"] = None
+        if hasattr(ctx, "bind_slab_boxes") and plan["vox"].numel() >= M and opt.slab_boxes:
+            # the scatters merge boxes the traversal left
+            plan["slab_table"] = ctx.bind_slab_boxes(plan["vox"])
+        # the plan path (one C call per phase, no combine kernel, maps into plan-owned host
+        # buffers): every image casts the same ray list in one launch, all columns resident
+        fast_ok = (opt.plan_path and hasattr(ctx, "scene_run") and shared is not None and V > 0 and
+                   not self.rays_batch and len(plan["groups"]) == 1 and not self.reference_quirks)
+        order = None
+        if fast_ok and not patch_rows and opt.sweep_reorder:
+            modes = {sweep_direction(H, W, [scene.get_image(v) for v in views_of[r]]) for r in refs}
+            if modes == {"rows"}:
+                order = row_major_order(shards[0][0], H, W) if shards[0][0].numel() else None
+            elif "rows" in modes:
+                fast_ok = False           # per-image schedules: the launch-by-launch path
+        if dist is not None and world > 1 and hasattr(ctx, "scene_run"):
+            # the two paths exchange differently (per-image all-gathers / one): every rank must
+            # take the same one, and a rank's HBM budget may have decided otherwise
+            t = torch.tensor([1 if fast_ok else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            fast_ok = bool(int(t.item()))
+        if fast_ok:
+            plan["fast"] = ctx.scene_plan(
+                V, npad, shards[0][0], plan["table"], cam_dev, plan["vox"], plan["rvc"],
+                plan["Sr"], plan["msgs"], plan["acc_a"], plan["acc_b"], plan["depth"],
+                plan["prior"], patch_rows, acc_fixed=plan["acc_part"] if plan["fixed"] else None,
+                order=order)
         if not self._filter_out_rays:
             self._plan = plan
         return plan
 
+    # -- where the maps land -------------------------------------------------------------------
+    def _epilogue_buffers(self, plan, refs, H, W, dev, world, collective):
+        """Plan-owned output side: per-image events, the device-side pixel-order maps, and TWO
+        sets of pinned host maps used alternately -- a pass allocates nothing.  The arrays a
+        pass yields are views of its set: they stay valid until the second-next pass over the
+        same plan (copy them to keep them longer; the reference's `.get()` hands out fresh
+        arrays, forward_pass.py:739-744)."""
+        if "host" in plan:
+            return
+        cuda = dev.type == "cuda"
+        V, HW = len(refs), H * W
+        plan["host"] = [torch.empty((V, HW), dtype=torch.float32, pin_memory=cuda) for _ in range(2)]
+        plan["host_np"] = [[h[k].numpy().reshape(W, H).T for k in range(V)] for h in plan["host"]]
+        plan["maps_dev"] = torch.zeros((V, HW), dtype=torch.float32, device=dev)
+        if cuda:
+            plan["ev_ready"] = [torch.cuda.Event() for _ in range(V)]
+            plan["ev_stitch"] = [torch.cuda.Event() for _ in range(V)]
+            plan["ev_done"] = [torch.cuda.Event() for _ in range(V)]
+            if self._side_stream is None:
+                self._side_stream, self._copy_stream = _side_streams(dev)
+        npad, lists, bounds = plan["npad"], plan["lists"], plan["bounds"]
+        if not collective:
+            # rows -> pixels: one index per image (rays that were filtered out stay 0)
+            plan["pix"] = [lists[r].long() for r in refs] if (
+                plan["patch_rows"] or self._filter_out_rays) else None
+        else:
+            # per image: the ranks' row blocks side by side (+ one zero for pixels without a
+            # ray) and the index that puts them into pixel order
+            plan["gathered"] = [torch.zeros((world * npad + 1,), dtype=torch.float32, device=dev)
+                                for _ in range(V)]
+            stitch = []
+            for k, r in enumerate(refs):
+                src = torch.full((HW,), world * npad, dtype=torch.int64, device=dev)
+                rays, cuts = lists[r].long(), bounds[k]
+                for q in range(world):
+                    lo_q, hi_q = cuts[q], cuts[q + 1]
+                    src[rays[lo_q:hi_q]] = q * npad + torch.arange(hi_q - lo_q, dtype=torch.int64,
+                                                                   device=dev)
+                stitch.append(src)
+            plan["stitch"] = stitch
+
+    def _emit_image(self, plan, k, st, dist, world, slot):
+        """Image k's depth rows (just enqueued on the current stream) -> pixel order -> pinned
+        host memory, on side streams: under the depth sweep of image k + 1.  Several ranks:
+        the all-gather of the ranks' row blocks (every rank sends only its own rows) runs on
+        the first side stream, the copy to the host on the second, so that image k + 1's
+        exchange does not wait for image k's PCIe transfer."""
+        host = plan["host"][slot][k]
+        rows = plan["depth"][st["row0"]:st["row0"] + (plan["npad"] if dist is not None else st["n"])]
+        side, copy = self._side_stream, self._copy_stream
+        plan["ev_ready"][k].record()
+        with torch.cuda.stream(side):
+            side.wait_event(plan["ev_ready"][k])
+            if dist is not None:
+                g = plan["gathered"][k]
+                dist.all_gather_into_tensor(g[:-1], rows)
+                torch.index_select(g, 0, plan["stitch"][k], out=plan["maps_dev"][k])
+                src = plan["maps_dev"][k]
+            elif plan["pix"] is not None:
+                plan["maps_dev"][k].index_copy_(0, plan["pix"][k], rows)
+                src = plan["maps_dev"][k]
+            else:
+                src = rows
+            plan["ev_stitch"][k].record()
+        with torch.cuda.stream(copy):
+            copy.wait_event(plan["ev_stitch"][k])
+            host.copy_(src, non_blocking=True)
+            plan["ev_done"][k].record()
+
+    def _exchange(self, plan, ctx, dist, world, it):
+        """The ranks' partial sums of BP iteration `it` become everybody's accumulator: ONE
+        all-reduce (float sums, or 64-bit fixed-point integers in the deterministic mode) --
+        or, deterministic mode with exchange="reduce_scatter", an int64 reduce-scatter, the
+        fixed -> float combine on the rank's own slab, and an all-gather of FLOATS (3/4 of the
+        all-reduce's bytes, the combine sharded N ways)."""
+        fast = plan["fast"]
+        if not plan["fixed"]:
+            if dist is not None:
+                dist.all_reduce(plan["acc_b" if it & 1 else "acc_a"], op=dist.ReduceOp.SUM)
+            return
+        part = plan["acc_part"]
+        out = plan["acc_b" if it & 1 else "acc_a"]
+        if dist is not None and self.options.exchange == "reduce_scatter" and \
+                part.numel() % (64 * world) == 0 and hasattr(ctx, "acc_combine_fixed_range"):
+            slab = part.numel() // world
+            if "slab_i" not in plan:
+                plan["slab_i"] = torch.empty((slab,), dtype=torch.int64, device=part.device)
+                plan["slab_f"] = torch.empty((slab,), dtype=torch.float32, device=part.device)
+            dist.reduce_scatter_tensor(plan["slab_i"], part, op=dist.ReduceOp.SUM)
+            part.zero_()
+            ctx.acc_combine_fixed_range(plan["slab_i"], plan["prior"], plan["slab_f"])
+            dist.all_gather_into_tensor(out, plan["slab_f"])
+            return
+        if dist is not None:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+        ctx.scene_run(fast, _lib.RN_RUN_COMBINE, it)
+
+    def _run_plan_path(self, plan, ctx, refs, dist, world):
+        """One pass as phases of the C plan (include/raynet_hip.h, rn_scene_run): 1 + T calls
+        for the K1 prefix and the T BP iterations, the exchange between them, then one depth
+        launch per image with its maps leaving under the next image's."""
+        fast, T = plan["fast"], self.bp_iterations
+        fixed = plan["fixed"]
+        if T == 0:
+            plan["msgs"].zero_()      # the depth sweep reads the initial, zero messages
+            ctx.scene_run(fast, _lib.RN_RUN_PREPARE)
+            if fixed:
+                plan["acc_b"].fill_(plan["prior"])
+            else:
+                plan["acc_b"].zero_()
+        for it in range(T):
+            ctx.scene_run(fast, (_lib.RN_RUN_PREPARE if it == 0 else 0) | _lib.RN_RUN_SWEEP, it)
+            self._exchange(plan, ctx, dist, world, it)
+        final = plan["acc_b" if (T - 1) & 1 else "acc_a"]
+        self._acc_flat, self._acc_bias = final, (0.0 if fixed else plan["prior"])
+        slot = plan["slot"] = plan["slot"] ^ 1
+        per_image = plan["per_image"]
+        for k, r in enumerate(refs):
+            ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, k)
+            self._emit_image(plan, k, per_image[r], dist, world, slot)
+        return slot
+
+    # -- the resident schedule ------------------------------------------------------------------
     def _forward_pass_resident(self, scene, images_range):
         start, end, skip = images_range
         gp = self._generation_params
@@ -571,30 +784,64 @@ class RayNetForwardPass(ForwardPass):
         dist, rank, world = _dist()
         # an initialised process group runs its collectives even when it has ONE rank (that is
         # how a single-GPU box exercises the RCCL path); no group, no collectives
-        collective = dist is not None
 
         bank = self._view_features(scene, refs)
         F = next(iter(bank.values())).shape[-1]
         ctx = self._context(scene, F)
         dev = ctx.device
-        bank = {v: f.to(dev, torch.float32).contiguous() for v, f in bank.items()}
-        prior = self._prior()
+        for v, f in bank.items():
+            if f.device != dev or f.dtype != torch.float32 or not f.is_contiguous():
+                bank[v] = f.to(dev, torch.float32).contiguous()
+        self._acc_flat = self._acc_grid = None
+        self._acc_bias = 0.0
+        plan = self._build_plan(scene, refs, bank, ctx, dist, rank, world)
+        self.shard_balance = plan["balance"]
+        if plan["slab_table"] is not None and not ctx.slab_boxes_bound_to(plan["vox"]):
+            # another driver object used the (shared) context in between
+            ctx.bind_slab_boxes(plan["vox"], plan["slab_table"])
+        elif plan["slab_table"] is None and hasattr(ctx, "bind_slab_boxes") and \
+                getattr(ctx, "_slab_boxes", None) is not None:
+            ctx.bind_slab_boxes(None)
+        per_image = plan["per_image"]
+        for r in refs:
+            self.ray_index[r] = per_image[r]["ridx"]
+        if self._side_stream is not None:      # an abandoned earlier pass may still be copying
+            torch.cuda.current_stream(dev).wait_stream(self._side_stream)
+            torch.cuda.current_stream(dev).wait_stream(self._copy_stream)
+
+        if plan["fast"] is not None:
+            self._epilogue_buffers(plan, refs, H, W, dev, world, dist is not None)
+            slot = self._run_plan_path(plan, ctx, refs, dist, world)
+            for r in refs:
+                st = per_image[r]
+                self.messages.put(r, st["msgs"], st["rvc"])
+                self.voxel_count[r] = st["rvc"]
+            maps = plan["host_np"][slot]
+            for k, r in enumerate(refs):
+                plan["ev_done"][k].synchronize()
+                self.ref_idx = r
+                yield maps[k]
+            return
+        for out in self._run_granular(scene, refs, bank, ctx, plan, dist, rank, world):
+            yield out
+
+    def _run_granular(self, scene, refs, bank, ctx, plan, dist, rank, world):
+        """The resident schedule launch by launch: ray batches (`rays_batch`), filtered ray lists,
+        memory-bounded groups of images, the reference's quirks, and back ends without the plan
+        entry (the host stand-in of the gloo tests).  Same results as the plan path."""
+        gp = self._generation_params
+        H, W = scene.image_shape
+        dev = ctx.device
+        collective = dist is not None
+        prior = plan["prior"]
         N = gp.neighbors + 1
         V = len(refs)
-        self._acc_flat = self._acc_grid = None
-        plan = self._build_plan(scene, refs, bank, ctx, dist, rank, world)
         cam_dev, views_of, lists, shards = plan["cam_dev"], plan["views_of"], plan["lists"], plan["shards"]
         npad, groups, patch_rows, fixed = plan["npad"], plan["groups"], plan["patch_rows"], plan["fixed"]
         vox_g, Sr_g, msgs_all, rvc_all = plan["vox"], plan["Sr"], plan["msgs"], plan["rvc"]
-        self.shard_balance = plan["balance"]
         # resident accumulators are flat buffers in the backend's own layout (4x4x4 bricks
         # on the GPU, include/raynet_hip.h); `self.accumulator` is handed out as [gx][gy][gz]
         acc_in, acc_next, acc_spare, acc_part = plan["acc_prior"], plan["acc_a"], plan["acc_b"], plan["acc_part"]
-        if self._side_stream is not None:      # an abandoned earlier pass may still be copying
-            torch.cuda.current_stream(dev).wait_stream(self._side_stream)
-        if plan["prior"] != prior:
-            plan["prior"] = prior
-            acc_in.fill_(prior)
         if plan["dirty"]:                      # an earlier pass was abandoned inside an iteration
             acc_part.zero_()
         if self.bp_iterations == 0 or self.reference_quirks:
@@ -602,10 +849,7 @@ class RayNetForwardPass(ForwardPass):
             # quirk Q2 decodes every image with the LAST image's rows, beyond that image's own
             # counts: the reference's zero-filled memmap is zero there
             msgs_all.zero_()
-
         per_image = plan["per_image"]
-        for r in refs:
-            self.ray_index[r] = per_image[r]["ridx"]
 
         def order_for(ridx_slice, lo_i, hi_i, images):
             # patch rows are already compact in both image directions (measured: the
@@ -714,7 +958,7 @@ class RayNetForwardPass(ForwardPass):
         pending = []
         if not collective:
             if cuda and self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=dev)
+                self._side_stream, self._copy_stream = _side_streams(dev)
             side = self._side_stream if cuda else None
             if side is not None:
                 depth_all.record_stream(side)
@@ -757,12 +1001,12 @@ class RayNetForwardPass(ForwardPass):
             # map depends on the ray lists and the sharding only: built once), ONE copy to the
             # host.  Pixels without a ray (filtered out) read the zero behind the blocks.
             HW = H * W
-            if plan["stitch"] is None:
+            if plan.get("stitch_all") is None:
                 # held by the plan: the gathers never write the zero behind the blocks
-                plan["gathered"] = torch.zeros((world * n_all + 1,), dtype=torch.float32, device=dev)
-            flat = plan["gathered"]
+                plan["gathered_all"] = torch.zeros((world * n_all + 1,), dtype=torch.float32, device=dev)
+            flat = plan["gathered_all"]
             dist.all_gather_into_tensor(flat[:-1], depth_all)
-            if plan["stitch"] is None:
+            if plan.get("stitch_all") is None:
                 src = torch.full((V * HW,), world * n_all, dtype=torch.int64, device=dev)
                 for k, r in enumerate(refs):
                     rays = lists[r].long()
@@ -772,8 +1016,8 @@ class RayNetForwardPass(ForwardPass):
                         src[k * HW + rays[lo_q:hi_q]] = (
                             q * n_all + k * npad +
                             torch.arange(hi_q - lo_q, dtype=torch.int64, device=dev))
-                plan["stitch"] = src
-            maps = flat.index_select(0, plan["stitch"])
+                plan["stitch_all"] = src
+            maps = flat.index_select(0, plan["stitch_all"])
             host = torch.empty((V * HW,), dtype=torch.float32, pin_memory=cuda)
             host.copy_(maps, non_blocking=True)
             done = torch.cuda.Event() if cuda else None

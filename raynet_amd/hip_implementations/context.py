@@ -29,11 +29,14 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def _chk(t, dtype, min_numel=0, name="tensor", optional=False, align=16):
+def _chk(t, dtype, min_numel=0, name="tensor", optional=False, align=4):
     """The C ABI takes raw device pointers: a tensor handed to it must be what the kernels
-    assume -- on the GPU, contiguous, of the stated dtype, at least `min_numel` elements, rows
-    `align`-byte aligned (16: the kernels read rows with 128-bit loads) -- or the call fails
-    HERE, not as a silent out-of-bounds access."""
+    assume -- on the GPU, contiguous, of the stated dtype, at least `min_numel` elements,
+    `align`-byte aligned -- or the call fails HERE, not as a silent out-of-bounds access.
+    Per-ray index / count arrays (ray_idxs, rvc, order, depth) are read element by element:
+    4 bytes, so that any slice of them (a ray batch of 50, an odd shard bound) is accepted like
+    the reference accepts it; the [n][M] row arrays are read with 128-bit accesses where M is a
+    multiple of 4 (`HipContext._row_align`) and only then need 16."""
     if t is None:
         if optional:
             return t
@@ -94,12 +97,31 @@ class HipContext(object):
         self.grid_shape = tuple(grid_shape)
         self.G = grid_shape[0] * grid_shape[1] * grid_shape[2]
         self.feature_shape = (self.N, self.H + self.padding + 1, self.W + self.padding + 1, self.F)
+        # rows of the [n][M] arrays start 16-byte aligned iff M % 4 == 0 -- exactly when the
+        # kernels use their 128-bit row accesses (k_traverse's flush, k_scatter_slab's loads)
+        self._row_align = 16 if self.M % 4 == 0 else 4
         handle = ctypes.c_void_p()
         rc = self.lib.rn_create(ctypes.byref(cfg), ctypes.byref(handle))
         if rc != _lib.RN_OK:
             raise _lib.RaynetHipError("rn_create failed: %s" % _lib.STATUS.get(rc, rc))
         self._h = handle
         self._grid_set = False
+        self._options = None
+
+    def set_options(self, options):
+        """Apply a PathOptions' context half (rn_options); a no-op when nothing changed."""
+        want = options.context_options()
+        if self._options == want:
+            return
+        o = _lib.Options(*want)
+        self._check(self.lib.rn_set_options(self._h, ctypes.byref(o)))
+        self._options = want
+
+    def get_options(self):
+        o = _lib.Options()
+        self._check(self.lib.rn_get_options(self._h, ctypes.byref(o)))
+        return dict(scatter_mode=o.scatter_mode, box_level=o.box_level, box_pin=bool(o.box_pin),
+                    overlap=o.overlap, generic_sweep=bool(o.generic_sweep))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -129,20 +151,28 @@ class HipContext(object):
     def scatter_reset(self):
         self._check(self.lib.rn_scatter_reset(self._h))
 
-    def bind_slab_boxes(self, vox):
+    def bind_slab_boxes(self, vox, table=None):
         """Let rn_scene_prepare_all keep slab boxes for the list buffer `vox` ([rows][M] i32;
         None unbinds): the scatters of a pass then merge boxes instead of scanning the lists
-        (include/raynet_hip.h).  The scratch table lives with the context."""
+        (include/raynet_hip.h).  Returns the scratch table (pass it back in to re-bind the same
+        buffer later: contexts are shared, the binding is the last caller's)."""
         if vox is None:
             self._check(self.lib.rn_scene_bind_slab_boxes(self._h, None, 0, None))
             self._slab_boxes = None
-            return
-        _chk(vox, torch.int32, self.M, "vox")
+            return None
+        _chk(vox, torch.int32, self.M, "vox", align=self._row_align)
         rows = vox.numel() // self.M
         size = int(self.lib.rn_slab_boxes_size(self._h, rows))
-        self._slab_boxes = (torch.empty((size,), dtype=torch.int32, device=self.device), vox)
-        self._check(self.lib.rn_scene_bind_slab_boxes(self._h, _ptr(vox), rows,
-                                                      _ptr(self._slab_boxes[0])))
+        if table is None:
+            table = torch.empty((size,), dtype=torch.int32, device=self.device)
+        _chk(table, torch.int32, size, "slab-box table", align=8)
+        self._slab_boxes = (table, vox)
+        self._check(self.lib.rn_scene_bind_slab_boxes(self._h, _ptr(vox), rows, _ptr(table)))
+        return table
+
+    def slab_boxes_bound_to(self, vox):
+        sb = getattr(self, "_slab_boxes", None)
+        return sb is not None and sb[1] is vox
 
     def scatter_state(self):
         """-> (tile level in use, chunks, overflowed chunks of the last counted launch)"""
@@ -365,11 +395,13 @@ class HipContext(object):
         f32, i32 = torch.float32, torch.int32
         fdim = self.feature_shape[1] * self.feature_shape[2] * self.F
         for k, fv in enumerate(feature_views):
-            _chk(fv, f32, fdim, "feature map %d" % k)
+            _chk(fv, f32, fdim, "feature map %d" % k, align=16)
         _chk(ray_idxs, i32, n, "ray_idxs"); _chk(order, i32, n, "order", optional=True)
-        _chk(P, f32, 12 * self.N, "P", align=4); _chk(P_inv, f32, 12, "P_inv", align=4)
-        _chk(center, f32, 3, "center", align=4)
-        _chk(vox, i32, n * self.M, "vox"); _chk(rvc, i32, n, "rvc"); _chk(Sr, f32, n * self.M, "Sr")
+        _chk(P, f32, 12 * self.N, "P"); _chk(P_inv, f32, 12, "P_inv")
+        _chk(center, f32, 3, "center")
+        ra = self._row_align
+        _chk(vox, i32, n * self.M, "vox", align=ra); _chk(rvc, i32, n, "rvc")
+        _chk(Sr, f32, n * self.M, "Sr", align=ra)
         assert order is None or len(order) == n
         arr = (ctypes.c_void_p * self.N)(*[fv.data_ptr() for fv in feature_views])
         self._check(self.lib.rn_scene_prepare(self._h, n, _ptr(ray_idxs), arr, _ptr(P),
@@ -385,22 +417,62 @@ class HipContext(object):
         f32, i32 = torch.float32, torch.int32
         _chk(feature_table, torch.int64, n_images * self.N, "feature_table", align=8)
         assert tuple(feature_table.shape) == (n_images, self.N)
-        _chk(cameras, f32, n_images * (12 * self.N + 16), "cameras", align=4)
+        _chk(cameras, f32, n_images * (12 * self.N + 16), "cameras")
         assert tuple(cameras.shape) == (n_images, 12 * self.N + 16)
         _chk(ray_idxs, i32, n, "ray_idxs"); _chk(order, i32, n, "order", optional=True)
-        _chk(vox, i32, rows * self.M, "vox"); _chk(rvc, i32, rows, "rvc")
-        _chk(Sr, f32, rows * self.M, "Sr")
+        ra = self._row_align
+        _chk(vox, i32, rows * self.M, "vox", align=ra); _chk(rvc, i32, rows, "rvc")
+        _chk(Sr, f32, rows * self.M, "Sr", align=ra)
         assert order is None or len(order) == n
         self._check(self.lib.rn_scene_prepare_all(
             self._h, int(n_images), n, int(rows_per_image), _ptr(ray_idxs),
             _ptr(feature_table), _ptr(cameras), _ptr(order), _ptr(vox), _ptr(rvc), _ptr(Sr),
             _ptr(self._segments(rows)), _stream()))
 
+    def scene_plan(self, n_images, rows_per_image, ray_idxs, feature_table, cameras, vox, rvc, Sr,
+                   msgs, acc0, acc1, depth, prior, patch_rows, acc_fixed=None, order=None):
+        """An rn_scene_plan over the caller's buffers, every tensor validated ONCE here; the
+        returned object (which keeps them alive) goes to scene_run."""
+        n, rows = len(ray_idxs), int(n_images) * int(rows_per_image)
+        f32, i32, ra = torch.float32, torch.int32, self._row_align
+        assert rows_per_image % 256 == 0 and n <= rows_per_image
+        _chk(feature_table, torch.int64, n_images * self.N, "feature_table", align=8)
+        assert tuple(feature_table.shape) == (n_images, self.N)
+        _chk(cameras, f32, n_images * (12 * self.N + 16), "cameras")
+        assert tuple(cameras.shape) == (n_images, 12 * self.N + 16)
+        _chk(ray_idxs, i32, n, "ray_idxs"); _chk(order, i32, n, "order", optional=True)
+        _chk(vox, i32, rows * self.M, "vox", align=ra); _chk(rvc, i32, rows, "rvc")
+        _chk(Sr, f32, rows * self.M, "Sr", align=ra); _chk(msgs, f32, rows * self.M, "msgs", align=ra)
+        _chk(depth, f32, rows, "depth")
+        G = self.acc_size()
+        _chk(acc0, f32, G, "acc[0]", align=16); _chk(acc1, f32, G, "acc[1]", align=16)
+        _chk(acc_fixed, torch.int64, G, "acc_fixed", optional=True, align=16)
+        seg = self._segments(rows)
+        pl = _lib.ScenePlan()
+        pl.n_images, pl.n, pl.rows_per_image = int(n_images), n, int(rows_per_image)
+        pl.ray_idxs, pl.order = ray_idxs.data_ptr(), (order.data_ptr() if order is not None else None)
+        pl.features_views, pl.cameras = feature_table.data_ptr(), cameras.data_ptr()
+        pl.vox, pl.rvc, pl.Sr, pl.msgs = vox.data_ptr(), rvc.data_ptr(), Sr.data_ptr(), msgs.data_ptr()
+        pl.ray_segments = seg.data_ptr()
+        pl.acc[0], pl.acc[1] = acc0.data_ptr(), acc1.data_ptr()
+        pl.acc_fixed = acc_fixed.data_ptr() if acc_fixed is not None else None
+        pl.depth, pl.prior = depth.data_ptr(), float(prior)
+        pl.row_layout = 1 if patch_rows else 0
+        pl._keepalive = (ray_idxs, feature_table, cameras, vox, rvc, Sr, msgs, acc0, acc1, depth,
+                         acc_fixed, order, seg)
+        pl._ref = ctypes.byref(pl)
+        return pl
+
+    def scene_run(self, plan, phases, iteration=0, image=-1):
+        """rn_scene_run: the phases (a mask of _lib.RN_RUN_*) of one pass, one C call."""
+        self._check(self.lib.rn_scene_run(self._h, plan._ref, int(phases), int(iteration),
+                                          int(image), _stream()))
+
     def count_voxels(self, ray_idxs, cameras):
         """-> int32 [n_images, n]: voxels crossed by every ray of ray_idxs in every reference
         image (rn_scene_count_voxels; cameras as for scene_prepare_all)."""
         n_images, n = int(cameras.shape[0]), len(ray_idxs)
-        _chk(cameras, torch.float32, n_images * (12 * self.N + 16), "cameras", align=4)
+        _chk(cameras, torch.float32, n_images * (12 * self.N + 16), "cameras")
         _chk(ray_idxs, torch.int32, n, "ray_idxs")
         out = torch.zeros((n_images, n), dtype=torch.int32, device=self.device)
         self._check(self.lib.rn_scene_count_voxels(self._h, n_images, n, _ptr(ray_idxs),
@@ -410,10 +482,13 @@ class HipContext(object):
     def _chk_rows(self, Sr, vox, rvc, msgs, acc, part=None, part_dtype=torch.float32):
         n = len(rvc)
         f32, i32 = torch.float32, torch.int32
-        _chk(Sr, f32, n * self.M, "Sr"); _chk(vox, i32, n * self.M, "vox"); _chk(rvc, i32, n, "rvc")
-        _chk(msgs, f32, n * self.M, "msgs"); _chk(acc, f32, self.acc_size(), "accumulator")
+        ra = self._row_align
+        _chk(Sr, f32, n * self.M, "Sr", align=ra); _chk(vox, i32, n * self.M, "vox", align=ra)
+        _chk(rvc, i32, n, "rvc")
+        _chk(msgs, f32, n * self.M, "msgs", align=ra)
+        _chk(acc, f32, self.acc_size(), "accumulator", align=16)
         if part is not None:
-            _chk(part, part_dtype, self.acc_size(), "partial accumulator")
+            _chk(part, part_dtype, self.acc_size(), "partial accumulator", align=16)
         return n
 
     def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False,
@@ -433,10 +508,19 @@ class HipContext(object):
             1 if patch_rows else 0, _stream()))
 
     def acc_combine_fixed(self, acc_part_fixed, prior, acc_out):
-        _chk(acc_part_fixed, torch.int64, self.acc_size(), "partial accumulator")
-        _chk(acc_out, torch.float32, self.acc_size(), "accumulator")
+        _chk(acc_part_fixed, torch.int64, acc_out.numel(), "partial accumulator", align=16)
+        _chk(acc_out, torch.float32, 1, "accumulator", align=16)
+        assert acc_out.numel() == self.acc_size()
         self._check(self.lib.rn_acc_combine_fixed(self._h, _ptr(acc_part_fixed), float(prior),
                                                   _ptr(acc_out), _stream()))
+
+    def acc_combine_fixed_range(self, part_fixed, prior, out):
+        """fixed -> float on any slab: out[i] = prior + part_fixed[i] * 2^-32; zeroes the slab."""
+        n = part_fixed.numel()
+        _chk(part_fixed, torch.int64, n, "fixed-point slab", align=8)
+        _chk(out, torch.float32, n, "accumulator slab")
+        self._check(self.lib.rn_acc_combine_fixed_range(self._h, _ptr(part_fixed), n, float(prior),
+                                                        _ptr(out), _stream()))
 
     def acc_combine(self, acc_part, prior, acc_out):
         _chk(acc_part, torch.float32, self.acc_size(), "partial accumulator")

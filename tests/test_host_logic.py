@@ -81,3 +81,46 @@ def test_bench_timeline_shares_split_concurrent_launches():
     # no start times: sums of durations
     assert bench.timeline_shares(launches, []) == pytest.approx({"a": 2.0, "b": 2.0, "c": 1.0})
     assert bench.timeline_shares([], []) == {}
+
+
+def test_path_options_defaults_env_overrides_and_key():
+    """One object for every knob; the environment only overrides defaults, parsed in one place."""
+    from raynet_amd.hip_implementations.options import PathOptions, shard_alpha_for
+    d = PathOptions()
+    assert d.ray_tile == (16, 16) and d.overlap == 2 and not d.deterministic and d.plan_path
+    assert d.context_options() == (-1, 0, 0, 2, 0)
+    env = {"RAYNET_RAY_TILE": "0", "RAYNET_DETERMINISTIC": "1", "RAYNET_HIP_OVERLAP": "1",
+           "RAYNET_SHARD_ALPHA": "0.45", "RAYNET_RESIDENT_GB": "1.5", "RAYNET_SLAB_BOXES": "0",
+           "RAYNET_HIP_BOX_LEVEL": "1", "RAYNET_EXCHANGE": "reduce_scatter", "UNRELATED": "x"}
+    o = PathOptions.from_env(env)
+    assert o.ray_tile is None and o.deterministic and o.overlap == 1 and o.shard_alpha == 0.45
+    assert o.resident_gb == 1.5 and not o.slab_boxes and o.box_level == 1
+    assert o.exchange == "reduce_scatter"
+    assert PathOptions.from_env({"RAYNET_RAY_TILE": "8x32"}).ray_tile == (8, 32)
+    # explicit arguments beat the environment; None means "not given"
+    assert PathOptions.from_env(env, deterministic=False, overlap=None).deterministic is False
+    assert PathOptions.from_env(env, overlap=None).overlap == 1
+    # a value that differs changes the key (plans are keyed on it), replace() leaves the source
+    assert d.key() != o.key() and d.replace(box_pin=True).key() != d.key() and not d.box_pin
+    assert set(d.as_dict()) == {f for f in PathOptions.__dataclass_fields__ if f != "ENV"}
+    import json
+    json.dumps(o.as_dict())                      # bench.py echoes it
+    with pytest.raises(AssertionError):
+        PathOptions(shard="tiles")
+    # the balance constant follows the shape: plane-sweep work ~ N D per ray, BP work ~ voxels
+    assert 0.3 < shard_alpha_for(5, 64, 137.4) < 0.45
+    assert 0.55 < shard_alpha_for(9, 128, 270.0) < 0.8
+
+
+def test_forward_pass_object_carries_its_options():
+    from raynet_amd.common.generation_parameters import GenerationParameters
+    from raynet_amd.forward_pass import RayNetForwardPass
+    from raynet_amd.hip_implementations.options import PathOptions
+    gp = GenerationParameters()
+    fp = RayNetForwardPass(None, gp, "sample_in_bbox", (8, 8), 0, deterministic=True,
+                           options=PathOptions(ray_tile=(8, 32)))
+    assert fp.deterministic and fp.ray_tile == (8, 32)
+    fp.ray_tile = None                           # tests / tools flip single knobs on the object
+    assert fp.options.ray_tile is None and fp.options.deterministic
+    fp.deterministic = False
+    assert not fp.options.deterministic

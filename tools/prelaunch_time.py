@@ -14,7 +14,7 @@ fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0)
 for _ in range(3): list(fp.forward_pass(scene, (0, V, 1)))
 ctx = fp._ctx
 first = {}
-for name in ("scene_prepare_all", "scene_prepare"):
+for name in ("scene_run", "scene_prepare_all", "scene_prepare"):
     if hasattr(ctx, name):
         orig = getattr(ctx, name)
         def wrap(*a, _o=orig, **k):

@@ -18,10 +18,15 @@ if os.environ.get("RN_FLAGS"):      # A/B build of the library for this run only
 import raynet_amd.forward_pass as F
 from raynet_amd.common.generation_parameters import GenerationParameters
 from raynet_amd.synthetic import make_synthetic_scene
-H, W, V = 480, 640, 5
+# CONFIG=config4: BASELINE.json configs[3] (9 views, 128 planes, 256^3, M = 768)
+if os.environ.get("CONFIG", "config2") == "config4":
+    H, W, V, D_, M_, G_ = 480, 640, 9, 128, 768, 256
+else:
+    H, W, V, D_, M_, G_ = 480, 640, 5, 64, 384, 128
 scene, bank = make_synthetic_scene(H=H, W=W, n_views=V, F=32, padding=11, focal=1.5 * H, seed=1234)
-gp = GenerationParameters(depth_planes=64, neighbors=4, grid_shape=np.array([128] * 3, np.int32),
-                          max_number_of_marched_voxels=384, padding=11, gamma_mrf=0.05)
+gp = GenerationParameters(depth_planes=D_, neighbors=min(4, V - 1) if V <= 5 else V - 1,
+                          grid_shape=np.array([G_] * 3, np.int32),
+                          max_number_of_marched_voxels=M_, padding=11, gamma_mrf=0.05)
 
 
 class FakeDist(object):
@@ -32,6 +37,9 @@ class FakeDist(object):
 
     def all_reduce(self, t, op=None):
         pass
+
+    def reduce_scatter_tensor(self, out, inp, op=None):
+        out.copy_(inp.view(self.world, -1)[0])
 
     def all_gather_into_tensor(self, out, inp, async_op=False):
         out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
@@ -52,6 +60,9 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
                 pass
         for _ in range(3):
             step()
+        import gc
+        gc.collect()
+        gc.disable()        # a generation-2 collection is a 40 ms pause once every ~20 passes
         ctx = fp._ctx
         torch.cuda.synchronize()
         if not os.environ.get("NO_PROF"):      # what the per-launch event pairs themselves cost
