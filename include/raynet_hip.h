@@ -399,6 +399,15 @@ int rn_selftest_arith(rn_ctx *ctx, int32_t n, const float *a, float *out, void *
 int rn_selftest_quotient(rn_ctx *ctx, int32_t n, const float *x, const float *d, float *out,
                          void *stream);
 
+/* The same for the two shortcuts of the planes -> voxels mapping of the resident path
+ * (raynet_kernels.h: markstein_div, plane_index_from_table), which stand in for the division
+ * by |ray|^2 and for the plane walk of planes_voxels_mapping.cu:48-67.  out is [5][n]:
+ * a / b (IEEE), Markstein's quotient from RN(1 / b), 1.0 where the kernels use it (b within
+ * 2^-60 .. 2^60 and |a| < 2^60; the IEEE division elsewhere), the walk's plane index for clamp(t, 1e-4,
+ * 1 - 1e-4) with the context's D, the table look-up's. */
+int rn_selftest_mapping(rn_ctx *ctx, int32_t n, const float *a, const float *b, const float *t,
+                        float *out, void *stream);
+
 /* ---- differentiable MRF block (training) --------------
  * The reference builds this block from TensorFlow ops and lets autodiff
  * differentiate it (raynet/tf_implementations/forward_backward_pass.py:194-246,

@@ -35,7 +35,7 @@ constexpr int NXCD = 8;
 #define RN_XCD_CHUNK_SWEEP 0
 #endif
 #ifndef RN_XCD_CHUNK_BP
-#define RN_XCD_CHUNK_BP 64
+#define RN_XCD_CHUNK_BP 256
 #endif
 #ifndef RN_XCD_CHUNK_DEPTH
 #define RN_XCD_CHUNK_DEPTH 0
@@ -134,6 +134,25 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_quotient(int n, const float 
     out[i] = round_half_away(x[i] / d[i]);
     out[(size_t)n + i] = fast;
     out[2 * (size_t)n + i] = sure ? 1.0f : 0.0f;
+}
+// the mapping's two exact shortcuts next to the expressions they replace (rn_selftest_mapping)
+__global__ __launch_bounds__(BLOCK) void k_selftest_mapping(Params p, int n,
+                                                            const float *__restrict__ a,
+                                                            const float *__restrict__ b,
+                                                            const float *__restrict__ t,
+                                                            float *out) {
+    extern __shared__ float pos[];
+    for (int i = threadIdx.x; i <= p.D; i += BLOCK) pos[i] = 0.0f + i * p.plane_step;
+    __syncthreads();
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float y = 1.0f / b[i];
+    out[i] = a[i] / b[i];
+    out[(size_t)n + i] = markstein_div(a[i], b[i], y);
+    out[2 * (size_t)n + i] = markstein_ok(b[i]) && markstein_ok_dividend(a[i]) ? 1.0f : 0.0f;
+    const float tc = clampf(t[i], 1e-4f, 1 - 1e-4f);
+    out[3 * (size_t)n + i] = (float)plane_index_walk(tc, p.D, p.plane_step);
+    out[4 * (size_t)n + i] = (float)plane_index_from_table(pos, tc, p.D);
 }
 // resident (bricked) accumulator <-> the reference's [gx][gy][gz] array
 template <bool TO_GRID>
@@ -249,9 +268,9 @@ inline int fill_blocks(int64_t n) {
     int64_t b = (n + BLOCK - 1) / BLOCK;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
-inline size_t sweep_lds(const Params &p) {
-    return sizeof(float) * ((size_t)((p.gx + p.gy + p.gz + 3) & ~3) +
-                            (size_t)WAVES_PER_BLOCK * (p.D + p.M));
+inline size_t sweep_lds(const Params &p, int rows = 1) {
+    return sizeof(float) * ((size_t)((p.gx + p.gy + p.gz + 3) & ~3) + (size_t)((p.D + 4) & ~3) +
+                            (size_t)WAVES_PER_BLOCK * (p.D + (size_t)rows * p.M));
 }
 
 FeatureViews stacked_views(const Params &p, const float *features) {
@@ -275,16 +294,20 @@ struct SweepArgs {
     int64_t rows_per_image = 0;
     int n_images = 1;
     const float *seg = nullptr;     // [rows][8]: ray segments written by k_traverse
+    float *msgs_out = nullptr;      // MAPMODE 3: BP iteration 0's messages
+    float prior = 0.0f;
 };
 
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
 void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
     ProfScope prof(ctx, RN_K_SWEEP_MAP, a.n * a.n_images, st);
     hipLaunchKernelGGL((k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>),
-                       dim3(ray_blocks(a.n), a.n_images), dim3(BLOCK), sweep_lds(ctx->p), st,
+                       dim3(ray_blocks(a.n), a.n_images), dim3(BLOCK),
+                       sweep_lds(ctx->p, MAPMODE == 3 ? 3 : 1), st,
                        ctx->p, a.n, a.ray_idxs, a.fv, a.P, a.P_inv, a.cc, a.starts, a.ends, a.S_in,
                        ctx->axes, a.vox, a.rvc, a.S_planes, a.S_voxel, a.depth_from_planes,
-                       a.points, a.order, a.fv_table, a.cam_stride, a.rows_per_image, a.seg);
+                       a.points, a.order, a.fv_table, a.cam_stride, a.rows_per_image, a.seg,
+                       a.msgs_out, a.prior);
 }
 
 // pick the plane-sweep flavour: cooperative for F=32 and 2..9 views, generic otherwise
@@ -403,7 +426,7 @@ template <bool PACKED, bool CLIP_IN>
 int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
               const float *acc_in, const float *msgs_in, void *acc_out, float *msgs_out,
               hipStream_t st, bool patch_rows = false, bool fixed = false,
-              const AccMode &am = AccMode()) {
+              const AccMode &am = AccMode(), bool skip_bp = false) {
     // Patch-ordered rows start with the LDS-box scatter on 128-ray x 32-step tiles.  The
     // kernel counts the chunks whose bounding box did not fit its LDS budget; the count of
     // the previous launches is copied out asynchronously (it may lag a launch) and when too
@@ -429,9 +452,36 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     // runs (on the context's second stream) while the second half's messages are computed.
     const size_t M = (size_t)ctx->p.M, VW = PACKED ? 1 : 3;
     const bool split = ctx->overlap == 1 || (ctx->overlap == 2 && level >= 1 && level < LAST);
-    const int nA = split && PACKED && n >= 65536 ? (n / 2 + 255) / 256 * 256 : n;
-    launch_bp_kernel<PACKED, CLIP_IN>(ctx, nA, Sv, vox, rvc, acc_in, msgs_in, msgs_out, st, am, true);
-    RN_LAUNCH_CHECK(ctx);
+#ifdef RN_CHAIN_PIECES
+    // experiment (profiles/r03_exp_chain_pieces.txt): the rows in RN_CHAIN_PIECES pieces, each
+    // piece's scatter right behind its BP sweep, so that the scatter's reads of the messages
+    // (and of the voxel lists) find them in the L2 / Infinity Cache the sweep just filled
+    if (PACKED && !skip_bp && n >= 65536) {
+        const int piece = (n / RN_CHAIN_PIECES + 255) / 256 * 256;
+        bool first = true;
+        for (int r0 = 0; r0 < n; r0 += piece, first = false) {
+            const int m = min(piece, n - r0);
+            launch_bp_kernel<PACKED, CLIP_IN>(ctx, m, Sv + r0 * M, vox + r0 * M * VW, rvc + r0, acc_in,
+                                              msgs_in ? msgs_in + r0 * M : nullptr, msgs_out + r0 * M,
+                                              st, am, first);
+            RN_LAUNCH_CHECK(ctx);
+            launch_scatter_kernel<PACKED>(ctx, m, msgs_out + r0 * M, vox + r0 * M * VW, rvc + r0,
+                                          acc_out, st, level, fixed);
+            RN_LAUNCH_CHECK(ctx);
+        }
+        return RN_OK;
+    }
+#endif
+    const int nA = split && PACKED && n >= 65536 && !skip_bp ? (n / 2 + 255) / 256 * 256 : n;
+    if (skip_bp) {
+        // the messages are there already (the plane sweep wrote them); what k_bp would have
+        // cleared on the side is cleared here
+        if (am.zero)
+            RN_HIP(ctx, hipMemsetAsync(am.zero, 0, sizeof(float) * acc_floats(ctx), st));
+    } else {
+        launch_bp_kernel<PACKED, CLIP_IN>(ctx, nA, Sv, vox, rvc, acc_in, msgs_in, msgs_out, st, am, true);
+        RN_LAUNCH_CHECK(ctx);
+    }
     if (nA < n) {
         RN_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
         launch_bp_kernel<PACKED, CLIP_IN>(ctx, n - nA, Sv + nA * M, vox + nA * M * VW, rvc + nA, acc_in,
@@ -922,10 +972,23 @@ int rn_scene_prepare(rn_ctx *ctx, int32_t n, const int32_t *ray_idxs,
     return RN_OK;
 }
 
-int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_per_image,
-                         const int32_t *ray_idxs, const float *const *features_views,
-                         const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
-                         float *Sr, float *ray_segments, void *stream) {
+}  // extern "C"
+
+namespace {
+// LDS a workgroup of the plane sweep may take and still leave room for RN_SWEEP_MIN_WAVES
+// wavefronts per SIMD (4 per workgroup, 160 KB per CU)
+inline bool fold_fits(const Params &p) {
+    return sweep_lds(p, 3) <= (size_t)160 * 1024 / ((RN_SWEEP_MIN_WAVES * 4 + 3) / 4);
+}
+}  // namespace
+
+// rn_scene_prepare_all; with msgs_fold the plane sweep also writes BP iteration 0's messages
+// (k_sweep_map MAPMODE 3, first_sweep_messages)
+static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_per_image,
+                                  const int32_t *ray_idxs, const float *const *features_views,
+                                  const float *cameras, const int32_t *order, int32_t *vox,
+                                  int32_t *rvc, float *Sr, float *ray_segments, void *stream,
+                                  float *msgs_fold, float prior) {
     if (!ctx || n_images < 1 || n < 0 || rows_per_image < n || !ray_idxs || !features_views ||
         !cameras || !vox || !rvc || !Sr)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -971,7 +1034,13 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
         a.rows_per_image = rows_per_image;
         a.n_images = ng;
         a.seg = ray_segments ? ray_segments + row0 * 8 : nullptr;
-        launch_sweep<2, true>(ctx, a, true, st);
+        if (msgs_fold) {
+            a.msgs_out = msgs_fold + row0 * M;
+            a.prior = prior;
+            launch_sweep<3, true>(ctx, a, true, st);
+        } else {
+            launch_sweep<2, true>(ctx, a, true, st);
+        }
     };
     const bool split = ctx->overlap == 1 || (ctx->overlap == 2 && ctx->box_level == 1);
     const int gA = split && n_images >= 2 && (int64_t)n * n_images >= 65536
@@ -998,6 +1067,16 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
         RN_LAUNCH_CHECK(ctx);
     }
     return RN_OK;
+}
+
+extern "C" {
+
+int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_per_image,
+                         const int32_t *ray_idxs, const float *const *features_views,
+                         const float *cameras, const int32_t *order, int32_t *vox, int32_t *rvc,
+                         float *Sr, float *ray_segments, void *stream) {
+    return scene_prepare_all_impl(ctx, n_images, n, rows_per_image, ray_idxs, features_views, cameras,
+                                  order, vox, rvc, Sr, ray_segments, stream, nullptr, 0.0f);
 }
 
 int rn_scene_count_voxels(rn_ctx *ctx, int32_t n_images, int32_t n, const int32_t *ray_idxs,
@@ -1125,12 +1204,20 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
     if (rows > 0x7fffffff) return fail(ctx, RN_ERR_INVALID, "rn_scene_run: too many rows");
     hipStream_t st = S(stream);
     const int64_t G = acc_floats(ctx);
+    bool folded = false;
     if (phases & RN_RUN_PREPARE) {
         if (fixed) RN_HIP(ctx, hipMemsetAsync(pl->acc_fixed, 0, sizeof(int64_t) * G, st));
+#ifndef RN_NO_FOLD_FIRST_SWEEP
+        // K1 prefix and BP iteration 0 requested together: the plane sweep writes the first
+        // messages itself (one occupancy for every voxel, nothing to gather) while the column
+        // is still in LDS; SWEEP(0) below is then the scatter alone
+        folded = (phases & RN_RUN_SWEEP) && iteration == 0 && fold_fits(ctx->p);
+#endif
         if (pl->n > 0)
-        rc = rn_scene_prepare_all(ctx, pl->n_images, pl->n, pl->rows_per_image, pl->ray_idxs,
-                                  pl->features_views, pl->cameras, pl->order, pl->vox, pl->rvc,
-                                  pl->Sr, pl->ray_segments, stream);
+            rc = scene_prepare_all_impl(ctx, pl->n_images, pl->n, pl->rows_per_image, pl->ray_idxs,
+                                        pl->features_views, pl->cameras, pl->order, pl->vox,
+                                        pl->rvc, pl->Sr, pl->ray_segments, stream,
+                                        folded ? pl->msgs : nullptr, pl->prior);
         if (rc) return rc;
     }
     if (pl->n == 0) {
@@ -1151,7 +1238,8 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
         rc = launch_bp<true, false>(ctx, (int)rows, pl->Sr, pl->vox, pl->rvc,
                                     pl->acc[(iteration + 1) & 1], iteration == 0 ? nullptr : pl->msgs,
                                     fixed ? (void *)pl->acc_fixed : (void *)pl->acc[iteration & 1],
-                                    pl->msgs, st, pl->row_layout == RN_ROWS_PATCHES, fixed, am);
+                                    pl->msgs, st, pl->row_layout == RN_ROWS_PATCHES, fixed, am,
+                                    folded);
         if (rc) return rc;
     }
     if ((phases & RN_RUN_COMBINE) && fixed) {
@@ -1235,6 +1323,16 @@ int rn_selftest_quotient(rn_ctx *ctx, int32_t n, const float *x, const float *d,
     if (!ctx || n < 0 || !x || !d || !out) return fail(ctx, RN_ERR_INVALID, "bad argument");
     hipLaunchKernelGGL(k_selftest_quotient, dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream), n, x,
                        d, out);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_selftest_mapping(rn_ctx *ctx, int32_t n, const float *a, const float *b, const float *t,
+                        float *out, void *stream) {
+    if (ctx && n == 0) return RN_OK;
+    if (!ctx || n < 0 || !a || !b || !t || !out) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_selftest_mapping, dim3(thread_blocks(n)), dim3(BLOCK),
+                       sizeof(float) * (ctx->p.D + 1), S(stream), ctx->p, n, a, b, t, out);
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }

@@ -569,13 +569,53 @@ __host__ __device__ __forceinline__ int slab_box_count(int M) {
 //   * STAGED: the caller parked the ray's packed ids in vals[0 .. count) (k_sweep_map's
 //     LDS-DMA); a run-time choice between that and the global row turns the load into a flat
 //     load of a selected pointer.
-template <bool PACKED, bool FAST = false, bool STAGED = false>
+// TABLE (the resident path): the plane positions `0.0f + l * step`, l = 0 .. D, come from an LDS
+// table `pos` holding exactly those fp32 values, and
+//   * the walk becomes a count.  fl(t - a) > 0 iff t > a, and the positions increase with l, so
+//     the walk's answer is L* = #{l >= 1 : pos[l] < t}.  With X = t (D - 1): pos[l] < t iff
+//     l < X (1 + e), |e| < 2^-22 (the roundings of step, l * step), and g = (int)fl(t (D - 1))
+//     is floor(X (1 + e')), |e'| <= 2^-24; X <= D <= 4096 (rn_create), so both L* and g are
+//     floor(X) unless X is within 2^-10 of an integer m, and then both lie in {m - 1, m}:
+//     |L* - g| <= 1 always, i.e. L* = (a - 1) + [pos[a] < t] + [pos[a + 1] < t] with
+//     a = max(g, 1) -- two table entries decide, no loop (the reference's loop costs a
+//     divergent ~2 x 9 instructions here);
+//   * t = sum / |ray|^2 is formed as Markstein's correctly rounded quotient from ONE IEEE
+//     reciprocal per ray: y = RN(1 / b), q0 = RN(a y), r = a - b q0 (exact in the FMA),
+//     q = RN(q0 + r y) = RN(a / b) whenever nothing over- or underflows -- which `div_ok`
+//     (|ray|^2 within 2^-60 .. 2^60 and every lane's dividend below 2^60; quotients below 5e-5
+//     clamp to eps anyway) guarantees; the IEEE division otherwise.  rn_selftest_mapping puts both next to the reference forms.
+__device__ __forceinline__ float markstein_div(float a, float b, float y) {
+    const float q0 = a * y;
+    const float r = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(r, y, q0);
+}
+__device__ __forceinline__ bool markstein_ok(float b) {
+    return b >= 0x1p-60f && b <= 0x1p60f;
+}
+// ... and the dividend: below 2^60 the quotient cannot overflow (an infinite q0 makes r NaN)
+__device__ __forceinline__ bool markstein_ok_dividend(float a) {
+    return __builtin_fabsf(a) < 0x1p60f;
+}
+// first plane index of the walk (planes_voxels_mapping.cu:60-67) from the table, see above
+__device__ __forceinline__ int plane_index_from_table(const float *pos, float t, int D) {
+    const int a = max((int)(t * (D - 1)), 1);
+    return (a - 1) + (pos[a] < t ? 1 : 0) + (pos[a + 1] < t ? 1 : 0);
+}
+// ... and the reference's own walk, from anywhere at or below its answer
+__device__ __forceinline__ int plane_index_walk(float t, int D, float step) {
+    int L = max(0, (int)(t * (D - 1)) - 1);
+    while ((t - (0.0f + L * step) > 0) && (t - (0.0f + (L + 1) * step) > 0)) L++;
+    return L;
+}
+
+template <bool PACKED, bool FAST = false, bool STAGED = false, bool TABLE = false>
 __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
                                                       const float *__restrict__ axes,
                                                       const int32_t *__restrict__ vrow,
                                                       int count, const float s[3],
                                                       const float e[3], const float *Sl,
-                                                      float *vals, int lane, int n_staged = 0) {
+                                                      float *vals, int lane, int n_staged = 0,
+                                                      const float *pos = nullptr) {
     const float eps = 1e-4f;
     float ray[3], ray_norm = 0.0f;
 #pragma unroll
@@ -583,6 +623,8 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
 #pragma unroll
     for (int i = 0; i < 3; i++) ray_norm += ray[i] * ray[i];
     const float step = p.plane_step;       // the same IEEE quotient, once per context
+    const bool div_ok = TABLE && markstein_ok(ray_norm);      // (wave-uniform)
+    const float rcp_norm = TABLE ? 1.0f / ray_norm : 0.0f;    // RN(1 / b): an IEEE division
     int carry = 0;
     float total = 0.0f;
     for (int base = 0; base < count; base += WAVE) {
@@ -610,24 +652,31 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
             vd = axes[p.gx + p.gy + z];
             vd -= s[2];
             sum += ray[2] * vd;
-            t = clampf(sum / ray_norm, eps, 1 - eps);
-            // The walk's answer L* is the first L at which (t - L*step > 0 && t - (L+1)*step > 0)
-            // fails; both hold for every L below it, so the walk may start anywhere at or below
-            // L*.  With q = t / step, L* is ceil(q) - 1 up to the rounding of these fp32
-            // expressions when q is within ~1e-5 of an integer k (then k - 1 or k), and
-            // floor(t * (D - 1)) is floor(q) up to the same (k - 1 or k): one below it is
-            // never above L*, and is L* - 1 for all but those boundary cases -- one loop
-            // iteration instead of two (round 1 started two below).
-            L = max(0, (int)(t * (p.D - 1)) - 1);
-            while ((t - (0.0f + L * step) > 0) && (t - (0.0f + (L + 1) * step) > 0)) L++;
+            if (TABLE) {
+                float q;
+                if (div_ok && __all(markstein_ok_dividend(sum))) q = markstein_div(sum, ray_norm, rcp_norm);
+                else q = sum / ray_norm;
+                t = clampf(q, eps, 1 - eps);
+                L = plane_index_from_table(pos, t, p.D);
+            } else {
+                t = clampf(sum / ray_norm, eps, 1 - eps);
+                // The walk's answer L* is the first L at which (t - L*step > 0 && t - (L+1)*step > 0)
+                // fails; both hold for every L below it, so the walk may start anywhere at or below
+                // L*.  With q = t / step, L* is ceil(q) - 1 up to the rounding of these fp32
+                // expressions when q is within ~1e-5 of an integer k (then k - 1 or k), and
+                // floor(t * (D - 1)) is floor(q) up to the same (k - 1 or k): one below it is
+                // never above L*, and is L* - 1 for all but those boundary cases -- one loop
+                // iteration instead of two (round 1 started two below).
+                L = plane_index_walk(t, p.D, step);
+            }
         }
         int left = max(wave_scan_max(valid ? L : 0), carry);
         carry = lane63i(left);
         float val = 0.0f;
         if (valid) {
             const int right = left + 1;
-            float left_d = fabsf(t - (0.0f + left * step));
-            float right_d = fabsf(t - (0.0f + right * step));
+            float left_d = fabsf(t - (TABLE ? pos[left] : 0.0f + left * step));
+            float right_d = fabsf(t - (TABLE ? pos[right] : 0.0f + right * step));
             const float c1 = 1.0f - vdiv<FAST>(left_d, left_d + right_d);
             const float c2 = 1.0f - vdiv<FAST>(right_d, left_d + right_d);
             val = c1 * Sl[left] + c2 * Sl[right];

@@ -99,7 +99,7 @@ template <int NCH, bool PACKED, bool NT = false>
 __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
                                           const float *__restrict__ S,
                                           const int32_t *__restrict__ vox, const float *msgs, int r,
-                                          int count, int lane) {
+                                          int count, int lane, bool need_vox = true) {
     const float *Srow = S + (size_t)r * p.M;
     const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
     const float *mrow = msgs ? msgs + (size_t)r * p.M : nullptr;
@@ -115,8 +115,11 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
 #else
             R.sv[ch] = row_load<NT>(Srow, (unsigned)i);
 #endif
-            if (PACKED) R.pk[ch] = row_load<NT>(vrow, (unsigned)i);
-            else R.pk[ch] = load_packed<PACKED>(vrow, i);
+            // (a sweep over ONE constant accumulator value gathers nothing: no voxel row)
+            if (need_vox) {
+                if (PACKED) R.pk[ch] = row_load<NT>(vrow, (unsigned)i);
+                else R.pk[ch] = load_packed<PACKED>(vrow, i);
+            }
 #ifndef RN_EXP_NO_MSG
             if (mrow) R.mv[ch] = row_load<NT>(mrow, (unsigned)i);
 #endif
@@ -162,7 +165,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
                                        float *msgs_out, bool uniform_acc, float acc_bias,
                                        bool biased) {
     RayRows<NB> cur;
-    load_rows<NB, PACKED, RN_BP_NT>(p, cur, S, vox, msgs_in, r, count, lane);
+    load_rows<NB, PACKED, RN_BP_NT>(p, cur, S, vox, msgs_in, r, count, lane, !uniform_acc);
     // accumulator gather (depends on the voxel rows).  uniform_acc: every voxel holds
     // acc_in[0] (the first iteration starts from the prior everywhere) -- nothing to gather,
     // and with zero messages on top the occupancy is one constant for the whole sweep.

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
 // MAPMODE  0: write the plane column to S_planes [n][D]            (K7 / K9 / K10)
 //          1: map to voxels, write S_voxel = vals / sum             (K6 / K11 / K1 / K2 prefix)
 //          2: as 1, then clip_and_renorm (mrf_bp.cu:103-111) -> Sr  (resident-scene path)
-// Dynamic LDS: [axes gx+gy+gz][per wave: D plane column][per wave: M values]
+//          3: as 2, then BP iteration 0 of the ray (first_sweep_messages) -> msgs_out
+// Dynamic LDS: [axes gx+gy+gz][plane positions][per wave: D plane column, M values (3 M for 3)]
 // -DRN_PHASE_TIMERS: where a k_sweep_map wavefront's cycles go (tools/phase_timers.py);
 // every 16th ray adds the s_memtime deltas between the marks to g_phase[]
 #ifdef RN_PHASE_TIMERS
@@ -284,8 +285,62 @@ __device__ unsigned long long g_phase[16];
 #ifndef RN_SWEEP_MIN_WAVES
 #define RN_SWEEP_MIN_WAVES 6
 #endif
+// BP iteration 0 of one ray straight from its clipped + renormalised column, which the plane
+// sweep still holds in LDS when it stores it (mrf_bp.cu:88-177 with the prior in every voxel and
+// no messages yet: ONE occupancy for the whole ray, nothing to gather, nothing to read) -- the
+// first k_bp launch of a pass, which read the column and the voxel list back from HBM to do
+// exactly this, goes away.  Operation for operation bp_ray's const-occupancy path (same scans,
+// same carries, same order): the messages are the same bits, whichever kernel writes them.
+// col[i] = clipped value (renormalised by `inv_sum` here, stored to Sr_row as k_bp would read
+// it); ts_row / cex_row: two more LDS rows of M floats of this wavefront.
+__device__ __forceinline__ void first_sweep_messages(int count, int lane, float *col, float inv_sum,
+                                                     float *ts_row, float *cex_row, float prior,
+                                                     float *Sr_row, float *msg_row) {
+    const float o_const = occupancy_to_ray(prior, 0.0f);
+    float carryT = 1.0f, carryC = 0.0f;
+    for (int base = 0; base < count; base += WAVE) {
+        const int i = base + lane;
+        const bool valid = i < count;
+        float sv = 0.0f;
+        if (valid) {
+            sv = col[i] * inv_sum;
+            // streamed out, read again only by later kernels: keep it out of the L2 the feature
+            // gathers live in
+            __builtin_nontemporal_store(sv, Sr_row + i);
+        }
+        const float o = valid ? o_const : 0.0f;
+        const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
+        const float T = carryT * wave_shift1(incl, 1.0f);
+        carryT = carryT * lane63(incl);
+        const float ts = T * sv;
+        const float w = valid ? o * ts : 0.0f;
+        const float inclC = wave_scan_add(w);
+        const float cex = carryC + wave_shift1(inclC, 0.0f);
+        carryC = carryC + lane63(inclC);
+        if (valid) {
+            ts_row[i] = ts;
+            cex_row[i] = cex;
+            col[i] = w;
+        }
+    }
+    float carryS = 0.0f;
+    for (int base = ((count - 1) / WAVE) * WAVE; base >= 0; base -= WAVE) {
+        const int i = base + lane;
+        float tot;
+        const float suf = carryS + wave_suffix_excl(i < count ? col[i] : 0.0f, lane, tot);
+        carryS = carryS + tot;
+        if (i < count) col[i] = suf;
+    }
+    for (int i = lane; i < count; i += WAVE) {
+        const float cex = cex_row[i];
+        const float pos = cex + ts_row[i];
+        const float neg = cex + bp_div(col[i], 1.0f - o_const);
+        __builtin_nontemporal_store(bp_log(pos) - bp_log(neg), msg_row + i);    // (as k_bp's rows)
+    }
+}
+
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
-__global__ __launch_bounds__(BLOCK, (SIM == 2 && MAPMODE == 2 && NV >= 5 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
+__global__ __launch_bounds__(BLOCK, (SIM == 2 && MAPMODE >= 2 && NV >= 5 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
 void k_sweep_map(
     Params p, int n, const int32_t *__restrict__ ray_idxs, FeatureViews fv,
     const float *__restrict__ P, const float *__restrict__ P_inv, const float *__restrict__ cc,
@@ -294,7 +349,8 @@ void k_sweep_map(
     const int32_t *__restrict__ vox, const int32_t *__restrict__ rvc, float *S_planes,
     float *S_voxel, float *depth_from_planes, float *points,
     const int32_t *__restrict__ order, const float *const *__restrict__ fv_table, int cam_stride,
-    int64_t rows_per_image, const float *__restrict__ seg) {
+    int64_t rows_per_image, const float *__restrict__ seg, float *msgs_out, float prior) {
+    constexpr bool RESIDENT = MAPMODE >= 2;      // value-only divisions through the reciprocal
     if (rows_per_image > 0) {       // blockIdx.y = reference image of a scene-wide launch
         const int g = blockIdx.y;
         P += (size_t)g * cam_stride;
@@ -305,15 +361,21 @@ void k_sweep_map(
         rvc += (size_t)g * rows_per_image;
         S_voxel += (size_t)g * rows_per_image * p.M;
         if (seg) seg += (size_t)g * rows_per_image * 8;
+        if (MAPMODE == 3) msgs_out += (size_t)g * rows_per_image * p.M;
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int naxes = p.gx + p.gy + p.gz;
     float *axes = smem;
     const int wid = threadIdx.x >> 6;
-    float *Sl = smem + ((naxes + 3) & ~3) + wid * (p.D + p.M);
+    // [axes][plane positions 0 .. D (resident path)][per wave: D plane column, M values]
+    float *pos = smem + ((naxes + 3) & ~3);
+    float *Sl = pos + ((p.D + 4) & ~3) + wid * (p.D + (MAPMODE == 3 ? 3 : 1) * p.M);
     float *vals = Sl + p.D;
     if (MAPMODE != 0) {
         for (int i = threadIdx.x; i < naxes; i += BLOCK) axes[i] = axes_g[i];
+        // the very expression the walk evaluates (planes_voxels_mapping.cu:60-67), once per plane
+        if (RESIDENT)
+            for (int i = threadIdx.x; i <= p.D; i += BLOCK) pos[i] = 0.0f + i * p.plane_step;
         __syncthreads();
     }
     int lane;
@@ -351,7 +413,7 @@ void k_sweep_map(
         // resident path: the column of a ray with <= 1 voxels is never read (such rays send no
         // message, mrf_np.py:300, and their depth is that of voxel 0): no sweep for the rays
         // that miss the box (5 % of config 2's)
-        if (MAPMODE == 2 && count <= 1) return;
+        if (RESIDENT && count <= 1) return;
         if (PACKED) {
             typedef const __attribute__((address_space(1))) void *gptr;
             typedef __attribute__((address_space(3))) void *lptr;
@@ -368,15 +430,15 @@ void k_sweep_map(
         if (SIM == 1)
             sweep_generic(p, fv, fv_table, P, s, e, lane, Sl);
         else
-            sweep_coop<NV, LPS, MAPMODE == 2>(p, fv, fv_table, P, s, e, lane, Sl);
+            sweep_coop<NV, LPS, RESIDENT>(p, fv, fv_table, P, s, e, lane, Sl);
         wave_sync();
         RN_PHASE_MARK(2);                  // projection + feature gathers + pair sums
-        softmax_column<MAPMODE == 2>(p.D, lane, Sl);
+        softmax_column<RESIDENT>(p.D, lane, Sl);
     }
     wave_sync();
     RN_PHASE_MARK(3);                      // softmax
 #ifdef RN_EXP_SWEEP_NOMAP       // timing experiment only (wrong results): no planes -> voxels
-    if (MAPMODE == 2) return;
+    if (RESIDENT) return;
 #endif
 
     if (MAPMODE == 0) {
@@ -423,9 +485,14 @@ void k_sweep_map(
     if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the voxel row
     // MAPMODE 2 = the resident path: value-only divisions through the hardware reciprocal
     // (the plane index walk inside stays IEEE); MAPMODE 1 = K6 / K11, reference arithmetic
+#ifdef RN_MAP_WALK      // A/B knob: the reference's walk and IEEE division in the resident path too
+    constexpr bool MAP_TABLE = false;
+#else
+    constexpr bool MAP_TABLE = RESIDENT;
+#endif
     const float srsum =
-        map_planes_to_voxels<PACKED, MAPMODE == 2, PACKED>(p, axes, vrow, count, s, e, Sl, vals,
-                                                           lane, n_staged);
+        map_planes_to_voxels<PACKED, RESIDENT, PACKED, MAP_TABLE>(p, axes, vrow, count, s, e, Sl,
+                                                                  vals, lane, n_staged, pos);
     RN_PHASE_MARK(4);                      // planes -> voxels
     if (MAPMODE == 1) {
         for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
@@ -438,9 +505,15 @@ void k_sweep_map(
             sum += v;
         }
         sum = __builtin_amdgcn_rcpf(wave_sum(sum));
-        // streamed out, read again only by later kernels: keep it out of the L2 the feature
-        // gathers live in
-        for (int i = lane; i < count; i += WAVE) __builtin_nontemporal_store(vals[i] * sum, out + i);
+        if (MAPMODE == 3) {
+            first_sweep_messages(count, lane, vals, sum, vals + p.M, vals + 2 * p.M, prior, out,
+                                 msgs_out + (size_t)r * p.M);
+        } else {
+            // streamed out, read again only by later kernels: keep it out of the L2 the feature
+            // gathers live in
+            for (int i = lane; i < count; i += WAVE)
+                __builtin_nontemporal_store(vals[i] * sum, out + i);
+        }
     }
     RN_PHASE_MARK(5);                      // clip + renormalise + store
 #ifdef RN_PHASE_TIMERS

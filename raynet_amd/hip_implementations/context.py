@@ -308,6 +308,12 @@ class HipContext(object):
         self._check(self.lib.rn_selftest_quotient(self._h, x.numel(), _ptr(x), _ptr(d), _ptr(out),
                                                   _stream()))
 
+    def selftest_mapping(self, a, b, t, out):
+        """out[5][n]: a / b, Markstein's quotient, usable, the walk's plane index, the table's
+        (tests only)."""
+        self._check(self.lib.rn_selftest_mapping(self._h, a.numel(), _ptr(a), _ptr(b), _ptr(t),
+                                                 _ptr(out), _stream()))
+
     # -- thin wrappers; argument order is the header's ------------------------
     def fill_f32(self, t, value):
         self._check(self.lib.rn_fill_f32(self._h, _ptr(t), t.numel(), float(value), _stream()))

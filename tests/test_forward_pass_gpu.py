@@ -930,16 +930,18 @@ def test_per_launch_profiling_and_family_selection(torch):
     everything = ctx.prof_end()
     starts = list(ctx.prof_starts)
     names = [n for n, _, _ in everything]
-    # one traversal, one plane sweep, 3 x (bp, scatter, combine), one depth sweep per image
+    # one traversal, one plane sweep (which also writes BP iteration 0's messages: no k_bp
+    # launch for it), 3 scatters, 2 more BP sweeps, one depth sweep per image; no combine
     assert names.count("sweep_map") == 1 and names.count("traverse") == 1
-    assert names.count("bp") == 3 and names.count("scatter") == 3 and names.count("depth") == 3
+    assert names.count("bp") == 2 and names.count("scatter") == 3 and names.count("depth") == 3
+    assert names.count("acc") == 0
     assert all(ms > 0 for _, _, ms in everything) and len(starts) == len(everything)
     assert starts[0] == 0.0 and all(b >= a for a, b in zip(starts, starts[1:]))
     assert [r for n, r, _ in everything if n == "sweep_map"] == [3 * H * W]
     ctx.prof_begin(capacity=256, only=["bp"])
     list(fp.forward_pass(scene, refs))
     only_bp = ctx.prof_end()
-    assert [n for n, _, _ in only_bp] == ["bp"] * 3
+    assert [n for n, _, _ in only_bp] == ["bp"] * 2
     ctx.prof_begin(capacity=256)                   # the selection does not stick
     list(fp.forward_pass(scene, refs))
     assert len(ctx.prof_end()) == len(everything)

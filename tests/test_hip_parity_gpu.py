@@ -889,6 +889,72 @@ def test_exact_arithmetic_shortcuts(torch, oracle_mod):
     assert np.array_equal(out[0][fin], expect.astype(np.float32)[fin])
 
 
+@pytest.mark.parametrize("D", [2, 3, 16, 64, 128, 1000, 4096])
+def test_mapping_shortcuts_are_exact(torch, D):
+    """The resident path's planes -> voxels mapping replaces (a) the division by |ray|^2 with
+    Markstein's correctly rounded quotient from one IEEE reciprocal per ray and (b) the plane
+    walk with a look-up in the table of the walk's own fp32 positions.  Bit for bit / index for
+    index against the expressions they replace: quotients of ordinary magnitudes, of the
+    extremes the range guard admits, and random bit patterns (where the guard is off, the
+    kernels divide); t planted within a few ulps of every plane position, random t, the
+    clamps' ends -- for plane counts from 2 to the 4096 rn_create admits."""
+    from raynet_amd.hip_implementations import get_context
+    ctx = get_context(M=64, D=D, N=2, F=4, H=8, W=8, padding=3, bbox=(0, 0, 0, 1, 1, 1),
+                      grid_shape=(4, 4, 4))
+    rng = np.random.default_rng(100 + D)
+    n = 1 << 21
+    q = n // 4
+    a = np.empty(n, np.float32)
+    b = np.empty(n, np.float32)
+    # (a) what the mapping divides: sums of a few products over |ray|^2, any sign
+    b[:q] = rng.uniform(1e-3, 50.0, q).astype(np.float32)
+    a[:q] = (rng.uniform(-1.5, 2.5, q) * b[:q]).astype(np.float32)
+    # (b) quotients next to representable results: a = RN(k * ulp-ish * b) nudged by +-2 ulps
+    b[q:2 * q] = rng.uniform(0.01, 20.0, q).astype(np.float32)
+    tq = rng.uniform(1e-4, 1.0, q).astype(np.float32)
+    aa = (tq * b[q:2 * q]).astype(np.float32)
+    a[q:2 * q] = (aa.view(np.int32) + rng.integers(-2, 3, q).astype(np.int32)).view(np.float32)
+    # (c) the guard's extremes: divisors 2^-60 .. 2^60, dividends down to where the clamp hides them
+    e = rng.integers(-60, 58, q)
+    b[2 * q:3 * q] = np.ldexp(rng.uniform(1.0, 2.0, q), e).astype(np.float32)
+    a[2 * q:3 * q] = (np.ldexp(rng.uniform(1.0, 2.0, q), e + rng.integers(-14, 2, q)) *
+                      rng.choice([-1.0, 1.0], q)).astype(np.float32)
+    # (d) anything
+    a[3 * q:] = rng.integers(0, 1 << 32, q, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    b[3 * q:] = rng.integers(0, 1 << 32, q, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    # t: every plane position of this D moved by -3 .. 3 ulps, the clamps, random
+    step = np.float32(1.0) / np.float32(D - 1)
+    pos = (np.float32(0.0) + np.arange(D + 1, dtype=np.float32) * step).astype(np.float32)
+    t = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    planted = (np.repeat(pos, 7).view(np.int32) + np.tile(np.arange(-3, 4, dtype=np.int32), D + 1))
+    planted = planted.view(np.float32)[:n // 2]
+    t[:planted.size] = planted
+    t[planted.size:planted.size + 8] = [0.0, 1e-4, 1.0, 1 - 1e-4, 2.0, -1.0, 9.9e-5, 0.99995]
+    out = torch.zeros((5, n), device="cuda")
+    ctx.selftest_mapping(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(),
+                         torch.from_numpy(t).cuda(), out)
+    exact, fast, ok, walk, table = out.cpu().numpy()
+    ok = ok > 0
+    assert ok[:3 * q].all()                         # everything a real ray produces is inside
+    same = (exact.view(np.uint32) == fast.view(np.uint32)) | (np.isnan(exact) & np.isnan(fast))
+    # where the result is clamped to eps anyway (|q| < 5e-5) a last-bit difference in the
+    # denormal range is invisible; everywhere else the two are the same bits
+    visible = np.abs(exact) >= 5e-5
+    bad = np.flatnonzero(ok & visible & ~same)
+    assert bad.size == 0, ("Markstein's quotient differs from the division", a[bad[:8]], b[bad[:8]],
+                           exact[bad[:8]], fast[bad[:8]])
+    with np.errstate(all="ignore"):
+        host = a / b
+    fin = np.isfinite(host)
+    assert np.array_equal(exact[fin], host[fin])    # the GPU's division is the host's (IEEE)
+    bad = np.flatnonzero(walk != table)
+    assert bad.size == 0, ("table look-up differs from the walk", t[bad[:8]], walk[bad[:8]],
+                           table[bad[:8]])
+    tc = np.clip(t, np.float32(1e-4), np.float32(1 - 1e-4))
+    expect = (pos[None, 1:D] < tc[:4096, None]).sum(1)          # #{l >= 1 : pos[l] < t}
+    assert np.array_equal(walk[:4096].astype(np.int64), expect)
+
+
 def test_rounded_quotient_shortcut(torch, oracle_mod):
     """round_quotient_fast (x * rcp(d), rounded) == roundf(x / d) bit for bit wherever it says
     it is sure: quotients planted within a few ulps of every rounding boundary k + 1/2 of a
