@@ -66,15 +66,24 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(kernel, n_rays, voxels, cfg, images=1):
+VALU_CLOCK_HZ = 2.4e9     # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, a wave64 VALU instruction = 4 cycles
+N_SIMDS = 1024
+
+
+def algorithmic_bytes(kernel, n_rays, voxels, cfg, images=1, folded=False, strict=False):
     """Algorithmic HBM bytes of ONE launch.  voxels = sum of the
-    per-ray voxel counts of the rays in the launch; images = reference images it covers."""
+    per-ray voxel counts of the rays in the launch; images = reference images it covers.
+    folded: the plane sweep also writes BP iteration 0's messages (4 B per voxel).
+    strict: SURVEY.md 8(d)'s own figure for the plane sweep -- the N feature maps once per
+    reference image and nothing else (a fused design need not materialise lists or columns)."""
     N, F = cfg["views"], cfg["F"]
     Hf, Wf = cfg["H"] + cfg["padding"] + 1, cfg["W"] + cfg["padding"] + 1
     if kernel == "traverse":      # write packed voxel list + count + ray segment, read ray index
         return 4 * voxels + 40 * n_rays
     if kernel == "sweep_map":     # N feature maps once; read voxel list + segment, write column
-        return images * 4 * N * F * Hf * Wf + 8 * voxels + 40 * n_rays
+        if strict:
+            return images * 4 * N * F * Hf * Wf
+        return images * 4 * N * F * Hf * Wf + (12 if folded else 8) * voxels + 40 * n_rays
     if kernel == "bp":            # Sr, voxel list, msg in, acc gather, msg out
         return 20 * voxels + 4 * n_rays
     if kernel == "scatter":       # msg, voxel list, atomic RMW of the accumulator (8)
@@ -223,10 +232,15 @@ def main():
                      max(1, sum(int(c.numel()) for c in counts.values())))
     cfg_acc = dict(cfg, views=gp.neighbors + 1)
 
+    # the plane sweep wrote BP iteration 0's messages itself when a step shows one k_bp launch
+    # fewer than BP iterations (rn_scene_run folds it when its LDS rows fit)
+    n_bp = sum(1 for name, _, _ in launches_all if name == "bp") / breakdown_steps
+    folded = n_bp < fp.bp_iterations - 0.5
+
     def account(recorded):
         fam = {}
         for name, n_rays, ms in recorded:
-            f = fam.setdefault(name, dict(ms=0.0, launches=0, bytes=0.0))
+            f = fam.setdefault(name, dict(ms=0.0, launches=0, bytes=0.0, strict=0.0))
             f["ms"] += ms
             f["launches"] += 1
             if n_rays:
@@ -234,8 +248,10 @@ def main():
                 vs = vox_by_n.get(n_rays)
                 vox = float(np.mean(vs)) if vs else mean_vox * n_rays
                 per_image = max(1, min(int(c.numel()) for c in counts.values())) if counts else n_rays
-                f["bytes"] += algorithmic_bytes(name, n_rays, vox, cfg_acc,
-                                                images=max(1, n_rays // per_image))
+                images = max(1, n_rays // per_image)
+                f["bytes"] += algorithmic_bytes(name, n_rays, vox, cfg_acc, images=images, folded=folded)
+                f["strict"] += algorithmic_bytes(name, n_rays, vox, cfg_acc, images=images,
+                                                 folded=folded, strict=True)
         return fam
 
     fam = account(launches_all)             # the breakdown steps: every family
@@ -247,22 +263,41 @@ def main():
         # HBM-side bytes per launch come from PMC counters, which need their own rocprofv3
         # passes (tools/pmc_passes.sh): the figure is read from the summary committed for
         # this configuration, never measured inside this run -- traffic_source says so
-        traffic = traffic_source = None
+        traffic = traffic_source = valu_insts = None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if world == 1 and os.path.exists(tpath):     # measured at N=1 launch sizes
             try:
-                tj = json.load(open(tpath))
-                if tj.get("_config", "config2") == args.config:
-                    traffic = tj.get(dominant)
+                tj = json.load(open(tpath)).get(args.config)
+                if tj is not None and dominant in tj["kernels"]:
+                    traffic = tj["kernels"][dominant]["traffic_bytes"]
+                    valu_insts = tj["kernels"][dominant].get("valu_insts")
                     traffic_source = "profiles/pmc_traffic.json (%s): separate rocprofv3 --pmc " \
-                                     "passes of this command, not this run" % tj.get("_profile", "r01_j")
+                                     "passes of this command, not this run" % tj["profile"]
             except Exception:
-                traffic = None
-        roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 1),
+                traffic = valu_insts = None
+        avg_ms = d["ms"] / d["launches"]
+        hbm_ms = d["bytes"] / d["launches"] / (HBM_PEAK_GBS * 1e9) * 1e3
+        # what binds the kernel: the time its algorithmic bytes need at the HBM peak, or the time
+        # its VALU instructions need to ISSUE (4 cycles each on one of 1024 SIMDs) -- counters
+        # from the same separate PMC passes as `traffic`
+        valu_issue_ms = valu_insts * 4.0 / (N_SIMDS * VALU_CLOCK_HZ) * 1e3 if valu_insts else None
+        strict = d["strict"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        roofline = dict(bound="valu" if (valu_issue_ms or 0.0) > hbm_ms else "hbm", kernel=dominant,
+                        achieved=round(achieved, 1),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                         traffic=traffic, traffic_source=traffic_source,
-                        avg_launch_ms=round(d["ms"] / d["launches"], 4), launches=d["launches"],
-                        algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]))
+                        avg_launch_ms=round(avg_ms, 4), launches=d["launches"],
+                        algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
+                        hbm_time_ms=round(hbm_ms, 4),
+                        valu_insts_per_launch=valu_insts,
+                        valu_issue_ms=round(valu_issue_ms, 4) if valu_issue_ms else None,
+                        valu_frac=round(valu_issue_ms / avg_ms, 4) if valu_issue_ms else None,
+                        strict_algorithmic=dict(
+                            what="SURVEY.md 8(d): the N feature maps once per reference image, no "
+                                 "lists / columns / messages",
+                            bytes_per_launch=int(d["strict"] / d["launches"]),
+                            achieved=round(strict, 1), frac=round(strict / HBM_PEAK_GBS, 4)),
+                        writes_first_messages=bool(folded) if dominant == "sweep_map" else None)
     kernels = {k: dict(total_ms_per_step=round(v["ms"] / breakdown_steps, 3),
                        timeline_share_ms_per_step=round(by_family.get(k, 0.0) / breakdown_steps, 3),
                        launches_per_step=v["launches"] / breakdown_steps,
@@ -377,7 +412,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config,
                        "rays_per_step": rays_per_step, "bp_iterations": 3,
-                       "schedule": args.schedule,
+                       "schedule": args.schedule, "options": fp.options.as_dict(),
                        "parallelism": "rays sharded x%d, 1 all-reduce/BP iteration" % world
                        if world > 1 else "single GPU",
                        "mean_voxels_per_ray": round(mean_vox, 2)},

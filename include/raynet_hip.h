@@ -399,6 +399,14 @@ int rn_selftest_arith(rn_ctx *ctx, int32_t n, const float *a, float *out, void *
 int rn_selftest_quotient(rn_ctx *ctx, int32_t n, const float *x, const float *d, float *out,
                          void *stream);
 
+/* The plane sweep's index arithmetic alone (feature_similarities.cu:10-61, 84-98): for every
+ * ray, view and depth plane the feature vector the sweep would gather, as fy * (W + padding + 1)
+ * + fx -- out [n][N][D][2]: by the generic sweep's expressions (the reference's, operation for
+ * operation) and by the cooperative sweep's (rounded quotients through the reciprocal where
+ * provably the same).  tests/ compares both with the reference's own NumPy `project`. */
+int rn_selftest_feature_offsets(rn_ctx *ctx, int32_t n, const float *P, const float *ray_start,
+                                const float *ray_end, int32_t *out, void *stream);
+
 /* The same for the two shortcuts of the planes -> voxels mapping of the resident path
  * (raynet_kernels.h: markstein_div, plane_index_from_table), which stand in for the division
  * by |ray|^2 and for the plane walk of planes_voxels_mapping.cu:48-67.  out is [5][n]:

@@ -141,6 +141,7 @@ SIGNATURES = {
     "rn_selftest_arith": [_P, _I, _P, _P, _P],
     "rn_selftest_quotient": [_P, _I, _P, _P, _P, _P],
     "rn_selftest_mapping": [_P, _I, _P, _P, _P, _P, _P],
+    "rn_selftest_feature_offsets": [_P, _I, _P, _P, _P, _P, _P],
     "rn_timer_start": [_P, _P],
     "rn_timer_stop": [_P, _P, ctypes.POINTER(_F)],
 }

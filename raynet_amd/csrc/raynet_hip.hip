@@ -135,6 +135,38 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_quotient(int n, const float 
     out[(size_t)n + i] = fast;
     out[2 * (size_t)n + i] = sure ? 1.0f : 0.0f;
 }
+// the plane sweep's index arithmetic on its own (rn_selftest_feature_offsets): lane = plane, as
+// in sweep_coop / sweep_generic
+__global__ __launch_bounds__(BLOCK) void k_selftest_offsets(Params p, int n,
+                                                            const float *__restrict__ P,
+                                                            const float *__restrict__ starts,
+                                                            const float *__restrict__ ends,
+                                                            int32_t *out) {
+    int lane;
+    const int r = ray_of_wave(n, lane);
+    if (r < 0) return;
+    float s[3], e[3];
+    for (int i = 0; i < 3; i++) {
+        s[i] = starts[3 * r + i];
+        e[i] = ends[3 * r + i];
+    }
+    const float pad_shift = (float)(p.padding - (p.padding - 1) / 2);
+    for (int base = 0; base < p.D; base += WAVE) {
+        const int k = min(base + lane, p.D - 1);        // (all lanes take part in the ballots)
+        float point[3];
+        plane_point(s, e, k, p.D, point);
+        for (int v = 0; v < p.N; v++) {
+            const int generic = feature_offset(p, P + 12 * v, point) / p.F;
+            // the cooperative sweep's form (128-byte vectors): byte offset -> vector index
+            const int coop = feature_offset_bytes<7>(p, P + 12 * v, point, pad_shift) >> 7;
+            if (base + lane < p.D) {
+                int32_t *o = out + (((size_t)r * p.N + v) * p.D + k) * 2;
+                o[0] = generic;
+                o[1] = coop;
+            }
+        }
+    }
+}
 // the mapping's two exact shortcuts next to the expressions they replace (rn_selftest_mapping)
 __global__ __launch_bounds__(BLOCK) void k_selftest_mapping(Params p, int n,
                                                             const float *__restrict__ a,
@@ -1323,6 +1355,17 @@ int rn_selftest_quotient(rn_ctx *ctx, int32_t n, const float *x, const float *d,
     if (!ctx || n < 0 || !x || !d || !out) return fail(ctx, RN_ERR_INVALID, "bad argument");
     hipLaunchKernelGGL(k_selftest_quotient, dim3(thread_blocks(n)), dim3(BLOCK), 0, S(stream), n, x,
                        d, out);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_selftest_feature_offsets(rn_ctx *ctx, int32_t n, const float *P, const float *ray_start,
+                                const float *ray_end, int32_t *out, void *stream) {
+    if (ctx && n == 0) return RN_OK;
+    if (!ctx || n < 0 || !P || !ray_start || !ray_end || !out)
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_selftest_offsets, dim3(ray_blocks(n)), dim3(BLOCK), 0, S(stream), ctx->p, n,
+                       P, ray_start, ray_end, out);
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }

@@ -308,6 +308,12 @@ class HipContext(object):
         self._check(self.lib.rn_selftest_quotient(self._h, x.numel(), _ptr(x), _ptr(d), _ptr(out),
                                                   _stream()))
 
+    def selftest_feature_offsets(self, P, starts, ends, out):
+        """out [n][N][D][2] int32: feature-vector index per ray / view / plane by the generic
+        and by the cooperative sweep's index arithmetic (tests only)."""
+        self._check(self.lib.rn_selftest_feature_offsets(self._h, len(starts), _ptr(P), _ptr(starts),
+                                                         _ptr(ends), _ptr(out), _stream()))
+
     def selftest_mapping(self, a, b, t, out):
         """out[5][n]: a / b, Markstein's quotient, usable, the walk's plane index, the table's
         (tests only)."""

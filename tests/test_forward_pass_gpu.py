@@ -603,8 +603,8 @@ def test_ragged_image_sizes_view_counts_and_tiles(torch, H, W, V, nb, tile):
 
 
 def test_full_size_parity_with_the_oracle(torch, oracle_mod):
-    """BASELINE.json config-2 size (480x640 rays, 64 planes, 128^3, M=384), two reference
-    images, per pixel: the HIP path against the C oracle run with the same schedule on the
+    """BASELINE.json config 2 in full (5 reference images of 480x640 rays, 64 planes, 128^3,
+    M=384), per pixel: the HIP path against the C oracle run with the same schedule on the
     host's cores.  The oracle uses its robust message form: the literal
     reference sequence overflows to +inf in a few voxels at this size, which is asserted too."""
     from raynet_amd.forward_pass import get_forward_pass_factory
@@ -613,14 +613,14 @@ def test_full_size_parity_with_the_oracle(torch, oracle_mod):
     scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
     gp = _gp(D, M, grid)
     fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0)
-    depth_hip = np.stack(list(fp.forward_pass(scene, (0, 2, 1))))
+    depth_hip = np.stack(list(fp.forward_pass(scene, (0, 5, 1))))
     acc_hip = fp.accumulator.cpu().numpy()
     o = oracle_mod.Oracle(M=M, D=D, N=5, F=32, H=H, W=W, padding=11, bbox=scene.bbox.ravel(),
                           grid_shape=grid, threads=oracle_mod.Oracle.max_threads())
     vg = oracle_mod.voxel_grid_centers(scene.bbox.ravel(), grid)
     ridx = np.arange(H * W, dtype=np.int32)
     cams = {}
-    for r in (0, 1):
+    for r in range(5):
         views = scene.view_indices_with_neighbors(r, 4)
         cams[r] = (bank.stacked(views).cpu().numpy(),
                    np.array([scene.get_image(v).camera.P for v in views], np.float32),
@@ -629,10 +629,10 @@ def test_full_size_parity_with_the_oracle(torch, oracle_mod):
 
     def run_oracle():
         acc = o.prior(0.05)
-        msgs = {r: np.zeros((H * W, M), np.float32) for r in (0, 1)}
+        msgs = {r: np.zeros((H * W, M), np.float32) for r in range(5)}
         for it in range(3):
             out = o.prior(0.05)
-            for r in (0, 1):
+            for r in range(5):
                 f, P, Pi, c = cams[r]
                 o.fused_bp(ridx, f, P, Pi, c, vg, acc, msgs[r], out)
             acc = out
@@ -643,8 +643,8 @@ def test_full_size_parity_with_the_oracle(torch, oracle_mod):
         acc, msgs = run_oracle()
         assert np.isfinite(acc).all()
         assert np.abs(acc_hip - acc).max() < 2e-5 * np.abs(acc).max()
-        inherited = 0
-        for r in (0, 1):
+        inherited = differing = 0
+        for r in range(5):
             f, P, Pi, c = cams[r]
             rvi_o, rvc_o, S_new, depth = o.fused_depth(ridx, f, P, Pi, c, vg, acc, msgs[r])
             d = np.abs(depth - depth_hip[r].T.ravel())
@@ -670,7 +670,10 @@ def test_full_size_parity_with_the_oracle(torch, oracle_mod):
                 d2 = o.depth_from_distribution(again, rvi_o[idx:idx + 1], vg, c)
                 assert abs(float(d2[0]) - float(depth_hip[r].T.ravel()[idx])) <= 1e-4, (r, idx)
                 inherited += 1
-            assert (d > 1e-4).sum() <= 20, int((d > 1e-4).sum())
+            differing += int((d > 1e-4).sum())
+        # observed: 4 - 5 of the scene's 1,536,000 pixels (profiles/r02_k_fullsize_parity.json),
+        # each a near-tie or inherited as proven above
+        assert differing <= 8, differing
         assert inherited <= 4, inherited
     finally:
         oracle_mod.Oracle.set_robust_messages(False)
