@@ -238,9 +238,10 @@ int64_t rn_slab_boxes_size(const rn_ctx *ctx, int64_t rows);
 int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int32_t *boxes);
 
 /* What the adaptive accumulator scatter of the resident path last saw (diagnostics): the tile
- * shape in use (0: 128 rays x 32 steps, 1: 256 x 16, 2: slab scatter) and, of the most recent
- * launch whose counters have arrived on the host, the number of tile chunks and how many of
- * them did not fit the LDS box. */
+ * shape in use (0: 128 rays x 32 steps, 1: 256 x 16, 2: slab scatter) and, of the launches
+ * between the launcher's last two looks at the counters that have arrived on the host (they are
+ * copied out for the first dozen scatters after a reset only), the number of tile chunks and how
+ * many of them did not fit the LDS box. */
 int rn_scatter_state(const rn_ctx *ctx, int32_t *level, uint32_t *chunks, uint32_t *overflowed);
 
 /* Voxel counts only (the traversal of rn_scene_prepare_all without its lists): rvc

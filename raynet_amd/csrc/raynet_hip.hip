@@ -14,6 +14,7 @@ using namespace rn;
 namespace {
 
 constexpr int BLOCK = 256;               // 4 wavefronts = 4 rays per workgroup
+constexpr int BOX_PROBE_LAUNCHES = 12;   // scatter launches after a reset whose overflow counters are read back
 // threads per workgroup of the wave-per-ray MRF kernels (k_bp, k_depth): A/B knob
 #ifndef RN_RAY_BLOCK
 #define RN_RAY_BLOCK 256
@@ -222,7 +223,15 @@ struct rn_ctx {
     // launches on the device and its pinned host mirror
     int box_level, box_level0;
     bool box_pin;         // RAYNET_HIP_BOX_PIN: stay at the starting level (A/B runs)
+    // device counters {chunks, overflowed chunks}, cumulative over launches; their pinned host
+    // mirror (an asynchronous copy, it may lag a launch); what the launcher had seen of them at
+    // its previous look; the difference = the launches in between (rn_scatter_state), and how
+    // many more launches copy the counters out: the tile shape settles within the first
+    // launches after a reset, and two 8-byte operations behind every scatter are two more
+    // dependent items on a stream whose kernels take 70 us each on an eight-rank shard
     unsigned *box_stats, *box_stats_host;
+    unsigned box_seen[2], box_obs[2];
+    int box_probe;
     hipEvent_t ev0, ev1;
     // second stream of the resident-scene launchers (RAYNET_HIP_OVERLAP=0 / 1, default: by
     // the scatter's tile level): the accumulator scatter of one half of a launch's rows runs
@@ -305,6 +314,11 @@ inline size_t sweep_lds(const Params &p, int rows = 1) {
                             (size_t)WAVES_PER_BLOCK * (p.D + (size_t)rows * p.M));
 }
 
+// floats of one resident (bricked) accumulator: every axis padded to a multiple of 4
+inline int64_t acc_floats(const rn_ctx *ctx) {
+    return (int64_t)((ctx->p.gx + 3) / 4) * ctx->p.nby * ctx->p.nbz * 64;
+}
+
 FeatureViews stacked_views(const Params &p, const float *features) {
     FeatureViews fv;
     const size_t dim = (size_t)p.Hf * p.Wf * p.F;
@@ -328,6 +342,7 @@ struct SweepArgs {
     const float *seg = nullptr;     // [rows][8]: ray segments written by k_traverse
     float *msgs_out = nullptr;      // MAPMODE 3: BP iteration 0's messages
     float prior = 0.0f;
+    float *zero = nullptr;          // MAPMODE 3: cleared on the side (rn_acc_size floats)
 };
 
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
@@ -339,7 +354,8 @@ void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
                        ctx->p, a.n, a.ray_idxs, a.fv, a.P, a.P_inv, a.cc, a.starts, a.ends, a.S_in,
                        ctx->axes, a.vox, a.rvc, a.S_planes, a.S_voxel, a.depth_from_planes,
                        a.points, a.order, a.fv_table, a.cam_stride, a.rows_per_image, a.seg,
-                       a.msgs_out, a.prior);
+                       a.msgs_out, a.prior, reinterpret_cast<float4 *>(a.zero),
+                       a.zero ? (int)(acc_floats(ctx) / 4) : 0);
 }
 
 // pick the plane-sweep flavour: cooperative for F=32 and 2..9 views, generic otherwise
@@ -362,11 +378,6 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
         }
     }
     launch_sweep_t<1, 1, 8, MAPMODE, PACKED>(ctx, a, st);
-}
-
-// floats of one resident (bricked) accumulator: every axis padded to a multiple of 4
-inline int64_t acc_floats(const rn_ctx *ctx) {
-    return (int64_t)((ctx->p.gx + 3) / 4) * ctx->p.nby * ctx->p.nbz * 64;
 }
 
 // the slab-box rows that describe `vox` (a pointer into the bound list buffer), or null
@@ -471,11 +482,17 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     constexpr int LAST = 2;
     int level = ctx->scatter_mode == 0 ? LAST : (ctx->scatter_mode == 2 || patch_rows) ? 0 : LAST;
     if (level == 0) {
-        const unsigned per = ctx->box_level < LAST - 1 ? 50u : 4u;
-        if (!ctx->box_pin && ctx->box_level < LAST && ctx->box_stats_host[0] > 0 &&
-            ctx->box_stats_host[1] * per > ctx->box_stats_host[0]) {
-            ctx->box_level++;
-            ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
+        const unsigned c0 = ctx->box_stats_host[0], c1 = ctx->box_stats_host[1];
+        if (c0 != ctx->box_seen[0]) {          // counters of more launches have arrived
+            ctx->box_obs[0] = c0 - ctx->box_seen[0];
+            ctx->box_obs[1] = c1 - ctx->box_seen[1];
+            ctx->box_seen[0] = c0;
+            ctx->box_seen[1] = c1;
+            const unsigned per = ctx->box_level < LAST - 1 ? 50u : 4u;
+            if (!ctx->box_pin && ctx->box_level < LAST && ctx->box_obs[1] * per > ctx->box_obs[0]) {
+                ctx->box_level++;
+                ctx->box_probe = BOX_PROBE_LAUNCHES;      // look at the new shape as well
+            }
         }
         level = ctx->box_level;
     }
@@ -505,12 +522,7 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     }
 #endif
     const int nA = split && PACKED && n >= 65536 && !skip_bp ? (n / 2 + 255) / 256 * 256 : n;
-    if (skip_bp) {
-        // the messages are there already (the plane sweep wrote them); what k_bp would have
-        // cleared on the side is cleared here
-        if (am.zero)
-            RN_HIP(ctx, hipMemsetAsync(am.zero, 0, sizeof(float) * acc_floats(ctx), st));
-    } else {
+    if (!skip_bp) {     // (else: the plane sweep wrote the messages and cleared am.zero)
         launch_bp_kernel<PACKED, CLIP_IN>(ctx, nA, Sv, vox, rvc, acc_in, msgs_in, msgs_out, st, am, true);
         RN_LAUNCH_CHECK(ctx);
     }
@@ -532,10 +544,10 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
         launch_scatter_kernel<PACKED>(ctx, n, msgs_out, vox, rvc, acc_out, st, level, fixed);
         RN_LAUNCH_CHECK(ctx);
     }
-    if (level < LAST) {
+    if (level < LAST && ctx->box_probe > 0) {
+        ctx->box_probe--;
         (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
                              hipMemcpyDeviceToHost, st);
-        (void)hipMemsetAsync(ctx->box_stats, 0, 2 * sizeof(unsigned), st);
     }
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
@@ -639,6 +651,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
         return RN_ERR_HIP;
     }
     ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
+    ctx->box_probe = BOX_PROBE_LAUNCHES;
     *out = ctx;
     return RN_OK;
 }
@@ -681,7 +694,8 @@ int rn_set_options(rn_ctx *ctx, const rn_options *opt) {
     ctx->box_pin = opt->box_pin != 0;
     ctx->overlap = opt->overlap;
     ctx->generic_sweep = opt->generic_sweep != 0;
-    ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
+    ctx->box_obs[0] = ctx->box_obs[1] = 0;
+    ctx->box_probe = BOX_PROBE_LAUNCHES;
     return RN_OK;
 }
 
@@ -926,7 +940,8 @@ int rn_acc_copies(const rn_ctx *ctx) { return ctx ? 1 : 0; }
 int rn_scatter_reset(rn_ctx *ctx) {
     if (!ctx) return RN_ERR_INVALID;
     ctx->box_level = ctx->box_level0;
-    ctx->box_stats_host[0] = ctx->box_stats_host[1] = 0;
+    ctx->box_obs[0] = ctx->box_obs[1] = 0;
+    ctx->box_probe = BOX_PROBE_LAUNCHES;
     return RN_OK;
 }
 
@@ -946,8 +961,8 @@ int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int3
 int rn_scatter_state(const rn_ctx *ctx, int32_t *level, uint32_t *chunks, uint32_t *overflowed) {
     if (!ctx || !level || !chunks || !overflowed) return RN_ERR_INVALID;
     *level = ctx->box_level;
-    *chunks = ctx->box_stats_host[0];
-    *overflowed = ctx->box_stats_host[1];
+    *chunks = ctx->box_obs[0];
+    *overflowed = ctx->box_obs[1];
     return RN_OK;
 }
 
@@ -1020,7 +1035,7 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
                                   const int32_t *ray_idxs, const float *const *features_views,
                                   const float *cameras, const int32_t *order, int32_t *vox,
                                   int32_t *rvc, float *Sr, float *ray_segments, void *stream,
-                                  float *msgs_fold, float prior) {
+                                  float *msgs_fold, float prior, float *zero_fold = nullptr) {
     if (!ctx || n_images < 1 || n < 0 || rows_per_image < n || !ray_idxs || !features_views ||
         !cameras || !vox || !rvc || !Sr)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -1069,6 +1084,7 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
         if (msgs_fold) {
             a.msgs_out = msgs_fold + row0 * M;
             a.prior = prior;
+            a.zero = g0 == 0 ? zero_fold : nullptr;      // (once per pass)
             launch_sweep<3, true>(ctx, a, true, st);
         } else {
             launch_sweep<2, true>(ctx, a, true, st);
@@ -1249,7 +1265,8 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
             rc = scene_prepare_all_impl(ctx, pl->n_images, pl->n, pl->rows_per_image, pl->ray_idxs,
                                         pl->features_views, pl->cameras, pl->order, pl->vox,
                                         pl->rvc, pl->Sr, pl->ray_segments, stream,
-                                        folded ? pl->msgs : nullptr, pl->prior);
+                                        folded ? pl->msgs : nullptr, pl->prior,
+                                        folded && !fixed ? pl->acc[0] : nullptr);
         if (rc) return rc;
     }
     if (pl->n == 0) {

@@ -165,9 +165,16 @@ __device__ __forceinline__ float round_half_away(float x) {
 __device__ __forceinline__ bool reciprocal_is_normal(float rcp_n) {
     return __builtin_amdgcn_classf(rcp_n, 0x108);    // -normal | +normal (v_cmp_class_f32)
 }
+// (Where it is sure, q' is not within 2^-21 |q'| of a half-way point, so ANY round-to-nearest
+// gives the integer roundf gives: v_rndne_f32, one instruction, stands in for the
+// three-instruction half-away form; an exact half-way q' has |q' - rndne(q')| = 1/2: not sure.)
 __device__ __forceinline__ float round_quotient_fast(float x, float rcp_n, bool &sure) {
     const float q = x * rcp_n;
+#ifdef RN_QUOTIENT_HALF_AWAY
     const float r = round_half_away(q);
+#else
+    const float r = __builtin_rintf(q);
+#endif
     sure = __builtin_fabsf(q - r) < __builtin_fmaf(__builtin_fabsf(q), -0x1p-21f, 0.5f);
     return r;
 }

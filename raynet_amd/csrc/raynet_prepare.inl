@@ -44,7 +44,7 @@ __global__ void k_sample_points(Params p, int n, const int32_t *__restrict__ ray
 #ifndef RN_TRAV_TILE
 #define RN_TRAV_TILE 16
 #endif
-constexpr int TRAV_TILE = RN_TRAV_TILE;     // steps collected per flush: 16, 32 or 64
+constexpr int TRAV_TILE = RN_TRAV_TILE;     // steps collected per flush (the packed list's slab boxes are per 16-step tile: k_traverse<true> needs 16; 32 / 64 compile for the reference layout only)
 template <bool PACKED>
 __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                                                    const int32_t *__restrict__ ray_idxs,
@@ -349,8 +349,17 @@ void k_sweep_map(
     const int32_t *__restrict__ vox, const int32_t *__restrict__ rvc, float *S_planes,
     float *S_voxel, float *depth_from_planes, float *points,
     const int32_t *__restrict__ order, const float *const *__restrict__ fv_table, int cam_stride,
-    int64_t rows_per_image, const float *__restrict__ seg, float *msgs_out, float prior) {
+    int64_t rows_per_image, const float *__restrict__ seg, float *msgs_out, float prior,
+    float4 *zero_buf, int zero_count4) {
     constexpr bool RESIDENT = MAPMODE >= 2;      // value-only divisions through the reciprocal
+    // MAPMODE 3 stands in for the first k_bp launch of a pass, including what that launch clears
+    // on the side: the partial accumulator the first scatter adds into (see k_bp)
+    if (MAPMODE == 3 && zero_buf && blockIdx.y == 0) {
+        const int nw = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+        const int w = blockIdx.x * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6);
+        for (int i = w * WAVE + (int)(threadIdx.x & (WAVE - 1)); i < zero_count4; i += nw * WAVE)
+            zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (rows_per_image > 0) {       // blockIdx.y = reference image of a scene-wide launch
         const int g = blockIdx.y;
         P += (size_t)g * cam_stride;
