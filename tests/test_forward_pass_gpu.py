@@ -368,6 +368,56 @@ def test_plan_path_equals_the_launch_by_launch_path(torch):
         assert np.abs(res[True, False][1] - res[True, True][1]).max() <= 5e-4
 
 
+def test_plan_is_keyed_on_geometry_and_refreshed_for_moved_features(torch):
+    """The plan of a pass is reused while cameras, neighbour selection, image range, shapes and
+    options stay the same; feature maps that moved (recomputed into new allocations) only refresh
+    the pointer table; a replaced camera, another image range or another option builds a new plan
+    (a stale camera table would silently cast the old rays)."""
+    from raynet_amd.common.camera import Camera
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.hip_implementations.options import PathOptions
+    from raynet_amd.synthetic import FeatureBank, make_synthetic_scene
+    H, W = 32, 48
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(16, 96, (32, 32, 32))
+    fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0,
+                                            options=PathOptions(deterministic=True))
+    d0 = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+    plan = fp._plan
+    vox_ptr = plan["vox"].data_ptr()
+    # the same maps at new addresses: same plan object, same buffers, refreshed table, same bits
+    moved = FeatureBank([bank.view_features(scene, v).clone() for v in range(5)])
+    fp._model = moved
+    d1 = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+    assert fp._plan is plan and plan["vox"].data_ptr() == vox_ptr
+    assert plan["table"].cpu().numpy().ravel()[0] == moved.view_features(scene, 0).data_ptr()
+    assert np.array_equal(d0, d1)
+    # other CONTENT at those addresses is picked up (nothing of a pass's results is cached)
+    moved.view_features(scene, 1).mul_(-1.0)
+    d2 = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+    assert fp._plan is plan and not np.array_equal(d1, d2)
+    moved.view_features(scene, 1).mul_(-1.0)
+    # a camera replaced in place (new object): new plan, other depths for that image
+    old = scene.get_image(0).camera
+    K2 = np.array(old.K, np.float64).copy()
+    K2[0, 0] *= 1.1
+    K2[1, 1] *= 1.1
+    scene.get_image(0).camera = Camera(K2, old.R, old.t)
+    d3 = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+    assert fp._plan is not plan and not np.array_equal(d3[0], d0[0])
+    scene.get_image(0).camera = old
+    d4 = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+    assert np.array_equal(d4, d0)
+    # another range / another option: new plans
+    plan = fp._plan
+    list(fp.forward_pass(scene, (0, 3, 1)))
+    assert fp._plan is not plan
+    plan = fp._plan
+    fp.ray_tile = None
+    list(fp.forward_pass(scene, (0, 3, 1)))
+    assert fp._plan is not plan and fp._plan["patch_rows"] is False
+
+
 def test_unaligned_slices_are_accepted(torch):
     """Per-ray arrays are read element by element: a ray batch of 50, an odd row offset, an M
     that is no multiple of 4 (rows then start 4-byte aligned only) all run -- the reference
