@@ -358,10 +358,13 @@ typedef enum {
     RN_RUN_PREPARE = 1,   /* traversal + plane sweep + mapping of all images (rn_scene_prepare_all) */
     RN_RUN_SWEEP = 2,     /* BP iteration `iteration` over all images: messages + scatter          */
     RN_RUN_COMBINE = 4,   /* deterministic mode: acc[iteration & 1] = prior + acc_fixed            */
-    RN_RUN_DEPTH = 8      /* depth sweep of image `image` (all images in one launch if < 0) after
+    RN_RUN_DEPTH = 8,     /* depth sweep of image `image` (all images in one launch if < 0) after
                              `iteration` BP iterations                                             */
+    RN_RUN_DEPTH_HEAD = 16 /* depth sweep of images [0, image) in ONE launch: a single GPU decodes
+                             all images but the last together (no launch tails between them) and
+                             the last one on its own, under which the others' maps leave        */
 } rn_run_phase;
-/* Runs the phases named in `phases` in the order PREPARE, SWEEP, COMBINE, DEPTH. */
+/* Runs the phases named in `phases` in the order PREPARE, SWEEP, COMBINE, DEPTH_HEAD / DEPTH. */
 int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *plan, int32_t phases, int32_t iteration,
                  int32_t image, void *stream);
 

@@ -310,6 +310,7 @@ class RayNetForwardPass(ForwardPass):
         self.shard_balance = None  # per image: traversed voxels of every rank's shard (world > 1)
         self.shard_alpha = None    # ... and the per-ray constant the cuts weighed rays with
         self._side_stream = self._copy_stream = None
+        self._pass_complete = True
         self.ref_idx = -1
         self._ctx = None
         self._de = None
@@ -768,6 +769,16 @@ class RayNetForwardPass(ForwardPass):
         self._acc_flat, self._acc_bias = final, (0.0 if fixed else plan["prior"])
         slot = plan["slot"] = plan["slot"] ^ 1
         per_image = plan["per_image"]
+        V = len(refs)
+        if dist is None and V >= 3 and self.options.depth_head:
+            # one GPU: all images but the last decoded by ONE launch (no launch tails between
+            # them), the last on its own -- long enough for the others' maps to leave under it
+            ctx.scene_run(fast, _lib.RN_RUN_DEPTH_HEAD, T, V - 1)
+            for k in range(V - 1):
+                self._emit_image(plan, k, per_image[refs[k]], dist, world, slot)
+            ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, V - 1)
+            self._emit_image(plan, V - 1, per_image[refs[V - 1]], dist, world, slot)
+            return slot
         for k, r in enumerate(refs):
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, k)
             self._emit_image(plan, k, per_image[r], dist, world, slot)
@@ -805,9 +816,12 @@ class RayNetForwardPass(ForwardPass):
         per_image = plan["per_image"]
         for r in refs:
             self.ray_index[r] = per_image[r]["ridx"]
-        if self._side_stream is not None:      # an abandoned earlier pass may still be copying
+        if self._side_stream is not None and not self._pass_complete:
+            # an abandoned earlier pass may still be copying (a pass consumed to its last map has
+            # waited for every one of its copies)
             torch.cuda.current_stream(dev).wait_stream(self._side_stream)
             torch.cuda.current_stream(dev).wait_stream(self._copy_stream)
+        self._pass_complete = False
 
         if plan["fast"] is not None:
             self._epilogue_buffers(plan, refs, H, W, dev, world, dist is not None)
@@ -817,10 +831,17 @@ class RayNetForwardPass(ForwardPass):
                 self.messages.put(r, st["msgs"], st["rvc"])
                 self.voxel_count[r] = st["rvc"]
             maps = plan["host_np"][slot]
+            spin = self.options.spin_wait
             for k, r in enumerate(refs):
-                plan["ev_done"][k].synchronize()
+                ev = plan["ev_done"][k]
+                if spin:
+                    while not ev.query():
+                        pass
+                else:
+                    ev.synchronize()
                 self.ref_idx = r
                 yield maps[k]
+            self._pass_complete = True
             return
         for out in self._run_granular(scene, refs, bank, ctx, plan, dist, rank, world):
             yield out

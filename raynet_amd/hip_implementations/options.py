@@ -36,6 +36,8 @@ class PathOptions:
     sweep_reorder: bool = True        # epipolar row-major schedule of the plane sweep for ray-index rows
     slab_boxes: bool = True           # the scatters merge the traversal's slab boxes instead of scanning
     plan_path: bool = True            # one C call per phase of a pass (rn_scene_run) when the pass qualifies
+    depth_head: bool = True           # one GPU: all images but the last decoded by one launch
+    spin_wait: bool = False           # poll the maps' events instead of blocking on them
     # ---- memory ---------------------------------------------------------------------------
     resident_gb: float = 0.0          # HBM budget of the resident schedule; 0: 90 % of what is free
     # ---- multi-GPU ------------------------------------------------------------------------
@@ -59,6 +61,8 @@ class PathOptions:
         "RAYNET_SWEEP_REORDER": ("sweep_reorder", _flag),
         "RAYNET_SLAB_BOXES": ("slab_boxes", _flag),
         "RAYNET_PLAN_PATH": ("plan_path", _flag),
+        "RAYNET_DEPTH_HEAD": ("depth_head", _flag),
+        "RAYNET_SPIN_WAIT": ("spin_wait", _flag),
         "RAYNET_RESIDENT_GB": ("resident_gb", float),
         "RAYNET_DETERMINISTIC": ("deterministic", _flag),
         "RAYNET_SHARD": ("shard", str),
