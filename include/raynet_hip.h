@@ -364,7 +364,9 @@ typedef enum {
                              all images but the last together (no launch tails between them) and
                              the last one on its own, under which the others' maps leave        */
 } rn_run_phase;
-/* Runs the phases named in `phases` in the order PREPARE, SWEEP, COMBINE, DEPTH_HEAD / DEPTH. */
+/* Runs the phases named in `phases` in the order PREPARE, SWEEP, COMBINE, DEPTH_HEAD / DEPTH.
+ * (The first PREPARE | SWEEP of iteration 0 with a given prior synchronises `stream` once: the one
+ * occupancy of that iteration is evaluated on the device and kept with the context.) */
 int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *plan, int32_t phases, int32_t iteration,
                  int32_t image, void *stream);
 

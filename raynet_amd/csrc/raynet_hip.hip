@@ -232,6 +232,10 @@ struct rn_ctx {
     unsigned *box_stats, *box_stats_host;
     unsigned box_seen[2], box_obs[2];
     int box_probe;
+    // occupancy_to_ray(prior, 0) as the device evaluates it, for the prior it was last asked for
+    float first_prior, first_occ;
+    bool have_first_occ;
+    float *scalar_dev;        // 4 bytes of device scratch owned by the context
     hipEvent_t ev0, ev1;
     // second stream of the resident-scene launchers (RAYNET_HIP_OVERLAP=0 / 1, default: by
     // the scatter's tile level): the accumulator scatter of one half of a launch's rows runs
@@ -341,7 +345,7 @@ struct SweepArgs {
     int n_images = 1;
     const float *seg = nullptr;     // [rows][8]: ray segments written by k_traverse
     float *msgs_out = nullptr;      // MAPMODE 3: BP iteration 0's messages
-    float prior = 0.0f;
+    float prior = 0.0f;             // MAPMODE 3: occupancy_to_ray(prior, 0), see first_occupancy()
     float *zero = nullptr;          // MAPMODE 3: cleared on the side (rn_acc_size floats)
 };
 
@@ -641,6 +645,7 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     }
     if (hipMalloc(&ctx->axes, sizeof(float) * (p.gx + p.gy + p.gz)) != hipSuccess ||
         hipMalloc(&ctx->box_stats, 2 * sizeof(unsigned)) != hipSuccess ||
+        hipMalloc(&ctx->scalar_dev, sizeof(float)) != hipSuccess ||
         hipHostMalloc(&ctx->box_stats_host, 2 * sizeof(unsigned)) != hipSuccess ||
         hipMemset(ctx->box_stats, 0, 2 * sizeof(unsigned)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
@@ -661,6 +666,7 @@ void rn_destroy(rn_ctx *ctx) {
     hipSetDevice(ctx->cfg.device);
     if (ctx->axes) hipFree(ctx->axes);
     if (ctx->box_stats) hipFree(ctx->box_stats);
+    if (ctx->scalar_dev) hipFree(ctx->scalar_dev);
     if (ctx->box_stats_host) hipHostFree(ctx->box_stats_host);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -1031,6 +1037,22 @@ inline bool fold_fits(const Params &p) {
 
 // rn_scene_prepare_all; with msgs_fold the plane sweep also writes BP iteration 0's messages
 // (k_sweep_map MAPMODE 3, first_sweep_messages)
+// The one occupancy of BP iteration 0 (the prior in every voxel, no messages), evaluated by the
+// device's own arithmetic once per prior value and kept with the context.
+static int first_occupancy(rn_ctx *ctx, float prior, hipStream_t st, float *out) {
+    if (!ctx->have_first_occ || ctx->first_prior != prior) {
+        hipLaunchKernelGGL(k_first_occupancy, dim3(1), dim3(1), 0, st, prior, ctx->scalar_dev);
+        hipError_t e = hipMemcpyAsync(&ctx->first_occ, ctx->scalar_dev, sizeof(float),
+                                      hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);      // (once per prior value)
+        if (e != hipSuccess) return fail(ctx, RN_ERR_HIP, "first_occupancy: %s", hipGetErrorString(e));
+        ctx->first_prior = prior;
+        ctx->have_first_occ = true;
+    }
+    *out = ctx->first_occ;
+    return RN_OK;
+}
+
 static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_per_image,
                                   const int32_t *ray_idxs, const float *const *features_views,
                                   const float *cameras, const int32_t *order, int32_t *vox,
@@ -1045,6 +1067,11 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
     const int N = ctx->p.N;
     const int cam_stride = 12 * N + 12 + 4;
     const size_t M = (size_t)ctx->p.M;
+    float o_first = 0.0f;
+    if (msgs_fold) {
+        rc = first_occupancy(ctx, prior, S(stream), &o_first);
+        if (rc) return rc;
+    }
     // slab boxes for the scatter, when a table is bound to this list buffer (rows_per_image is
     // then a multiple of 64 by the binding's contract: checked)
     int2 *boxes = rows_per_image % WAVE == 0
@@ -1083,7 +1110,7 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
         a.seg = ray_segments ? ray_segments + row0 * 8 : nullptr;
         if (msgs_fold) {
             a.msgs_out = msgs_fold + row0 * M;
-            a.prior = prior;
+            a.prior = o_first;
             a.zero = g0 == 0 ? zero_fold : nullptr;      // (once per pass)
             launch_sweep<3, true>(ctx, a, true, st);
         } else {

@@ -32,6 +32,9 @@ __global__ void k_sample_points(Params p, int n, const int32_t *__restrict__ ray
     }
 }
 
+// occupancy_to_ray(prior, 0) by the device's own arithmetic (see first_sweep_messages)
+__global__ void k_first_occupancy(float prior, float *out) { out[0] = occupancy_to_ray(prior, 0.0f); }
+
 // ------------------------------------------------------------ K5 traversal
 // One thread per ray (the DDA is a chain of sequential fp32 additions, bit-exactness
 // forbids re-associating it).  Source of the segment: explicit starts/ends, or the
@@ -294,9 +297,11 @@ __device__ unsigned long long g_phase[16];
 // col[i] = clipped value (renormalised by `inv_sum` here, stored to Sr_row as k_bp would read
 // it); ts_row / cex_row: two more LDS rows of M floats of this wavefront.
 __device__ __forceinline__ void first_sweep_messages(int count, int lane, float *col, float inv_sum,
-                                                     float *ts_row, float *cex_row, float prior,
+                                                     float *ts_row, float *cex_row, float o_const,
                                                      float *Sr_row, float *msg_row) {
-    const float o_const = occupancy_to_ray(prior, 0.0f);
+    // o_const = occupancy_to_ray(prior, 0): the same for every ray of every pass with this
+    // prior -- evaluated ONCE on the device (k_first_occupancy, the bits k_bp's own evaluation
+    // gives) and handed in, instead of ~30 instructions per wavefront
     float carryT = 1.0f, carryC = 0.0f;
     for (int base = 0; base < count; base += WAVE) {
         const int i = base + lane;
@@ -349,7 +354,7 @@ void k_sweep_map(
     const int32_t *__restrict__ vox, const int32_t *__restrict__ rvc, float *S_planes,
     float *S_voxel, float *depth_from_planes, float *points,
     const int32_t *__restrict__ order, const float *const *__restrict__ fv_table, int cam_stride,
-    int64_t rows_per_image, const float *__restrict__ seg, float *msgs_out, float prior,
+    int64_t rows_per_image, const float *__restrict__ seg, float *msgs_out, float o_first,
     float4 *zero_buf, int zero_count4) {
     constexpr bool RESIDENT = MAPMODE >= 2;      // value-only divisions through the reciprocal
     // MAPMODE 3 stands in for the first k_bp launch of a pass, including what that launch clears
@@ -515,7 +520,7 @@ void k_sweep_map(
         }
         sum = __builtin_amdgcn_rcpf(wave_sum(sum));
         if (MAPMODE == 3) {
-            first_sweep_messages(count, lane, vals, sum, vals + p.M, vals + 2 * p.M, prior, out,
+            first_sweep_messages(count, lane, vals, sum, vals + p.M, vals + 2 * p.M, o_first, out,
                                  msgs_out + (size_t)r * p.M);
         } else {
             // streamed out, read again only by later kernels: keep it out of the L2 the feature
