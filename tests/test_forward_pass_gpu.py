@@ -25,9 +25,9 @@ def _gp(D, M, grid, neighbors=4, padding=11):
                                 max_number_of_marched_voxels=M, padding=padding, gamma_mrf=0.05)
 
 
-def _oracle_forward(oracle_mod, scene, bank, gp, refs, H, W, iters=3, quirks=False):
+def _oracle_forward(oracle_mod, scene, bank, gp, refs, H, W, iters=3, quirks=False, F=32):
     o = oracle_mod.Oracle(M=gp.max_number_of_marched_voxels, D=gp.depth_planes,
-                          N=gp.neighbors + 1, F=32, H=H, W=W, padding=gp.padding,
+                          N=gp.neighbors + 1, F=F, H=H, W=W, padding=gp.padding,
                           bbox=scene.bbox.ravel(), grid_shape=gp.grid_shape,
                           threads=oracle_mod.Oracle.max_threads())
     vg = oracle_mod.voxel_grid_centers(scene.bbox.ravel(), gp.grid_shape)
@@ -978,11 +978,16 @@ def test_edge_ranges_and_zero_iterations(torch, oracle_mod):
         assert (np.abs(d0[r] - depths[r]) > 1e-4).mean() < 0.01
 
 
-@pytest.mark.parametrize("D,M,grid,nb", [(2, 96, (32, 32, 32), 4),        # the fewest planes
-                                          (48, 16, (32, 32, 32), 2),       # every ray truncated at M
-                                          (100, 96, (30, 33, 17), 3),      # 2 plane chunks, grid no multiple of the bricks
-                                          (64, 200, (64, 8, 64), 1)])      # flat grid, 2 views
-def test_resident_path_odd_shapes_vs_oracle(torch, oracle_mod, D, M, grid, nb):
+@pytest.mark.parametrize("D,M,grid,nb,F,pad", [
+    (2, 96, (32, 32, 32), 4, 32, 11),        # the fewest planes
+    (48, 16, (32, 32, 32), 2, 32, 11),       # every ray truncated at M
+    (100, 96, (30, 33, 17), 3, 32, 11),      # 2 plane chunks, grid no multiple of the bricks
+    (64, 200, (64, 8, 64), 1, 32, 11),       # flat grid, 2 views
+    (16, 96, (32, 32, 32), 2, 8, 5),         # F = 8: the generic sweep (incl. the folded first sweep)
+    (24, 64, (32, 32, 32), 3, 20, 7),        # F no power of two, 4 views
+    (32, 700, (160, 150, 170), 2, 32, 11),   # 11 list chunks: too long for the fold's LDS rows
+    (16, 1024, (200, 180, 190), 1, 32, 11)]) # the longest lists the library takes
+def test_resident_path_odd_shapes_vs_oracle(torch, oracle_mod, D, M, grid, nb, F, pad):
     """Plane counts that are no multiple of 64 (and the minimum, 2), lists cut off at M, grid
     sizes that are no multiple of the 4x4x4 accumulator bricks, 2 - 5 views: the resident
     schedule against the oracle's K1 / K2 schedule.  The planted surface makes these columns
@@ -994,13 +999,15 @@ def test_resident_path_odd_shapes_vs_oracle(torch, oracle_mod, D, M, grid, nb):
     from raynet_amd.forward_pass import get_forward_pass_factory
     from raynet_amd.synthetic import make_synthetic_scene
     H, W, V = 24, 32, 5
-    scene, bank = make_synthetic_scene(H=H, W=W, n_views=V, focal=1.5 * H)
-    gp = _gp(D, M, grid, neighbors=nb)
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=V, focal=1.5 * H, F=F, padding=pad)
+    gp = _gp(D, M, grid, neighbors=nb, padding=pad)
     fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0)
     depths = list(fp.forward_pass(scene, (0, 3, 1)))
+    assert fp._plan["fast"] is not None
     oracle_mod.Oracle.set_robust_messages(True)
     try:
-        acc, msgs, depths_o, dists = _oracle_forward(oracle_mod, scene, bank, gp, [0, 1, 2], H, W)
+        acc, msgs, depths_o, dists = _oracle_forward(oracle_mod, scene, bank, gp, [0, 1, 2], H, W,
+                                                     F=F)
     finally:
         oracle_mod.Oracle.set_robust_messages(False)
     cnt = fp.voxel_count[0].cpu().numpy()
