@@ -318,6 +318,10 @@ __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureView
 #ifndef RN_SWEEP_UNROLL2_MAX_VIEWS
 #define RN_SWEEP_UNROLL2_MAX_VIEWS 6
 #endif
+// views whose projection matrices may stay in SGPRs across the chunk loop (see sweep_coop)
+#ifndef RN_SWEEP_SGPR_VIEWS
+#define RN_SWEEP_SGPR_VIEWS 16
+#endif
 // x + (x of the lane the DPP control names), one VALU instruction, no LDS round trip.
 // quad_perm:[1,0,3,2] / [2,3,0,1] = xor 1 / xor 2; row_half_mirror pairs lane i with 7-i of
 // its group of 8, which sums the two quads once they are quad-uniform.
@@ -467,7 +471,17 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
 #ifdef RN_EXP_SWEEP_NOPROJ      // timing experiment only (wrong results): no projection arithmetic
                 offb[v] = (int)(((unsigned)(k * 977 + v * 131071 + lane * 8191) * 128u) & 0xffffffu);
 #else
-                offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, P + 12 * v, point, pad_shift);
+                // The 12 entries of a view's matrix are wave-uniform: scalar loads into SGPRs,
+                // all NV x 12 of them hoisted out of the chunk loop -- beyond 6 views more than
+                // there are: 125 SGPRs spilled at 9 views, ~300 v_writelane / v_readlane in the
+                // kernel.  (Reloading a view's matrix where it is used -- the pointer made
+                // opaque by an empty asm, for all or only the last views -- removes every spill
+                // and is 11 % SLOWER at config 4, 17.3 -> 19.3 ms: the scalar loads' latency
+                // lands in front of every view's projection, -DRN_SWEEP_SGPR_VIEWS=n; the matrices
+                // from LDS into VGPRs: 19 % slower, 20.5 ms.  profiles/r03_exp_view_matrix_sgprs.txt)
+                const float *Pv = P + 12 * v;
+                if (v >= RN_SWEEP_SGPR_VIEWS) asm volatile("" : "+s"(Pv));
+                offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, Pv, point, pad_shift);
 #endif
             }
         }
