@@ -18,7 +18,10 @@ region starts (the MV-CNN is outside the path); nothing is cached between steps.
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     dominant kernel family: algorithmic bytes of its
                launches in the timed region / their hipEvent durations (per launch, on
-               the launch stream, via rn_prof_begin/rn_prof_end), vs the 8 TB/s HBM peak
+               the launch stream, via rn_prof_begin/rn_prof_end), vs the 8 TB/s HBM peak;
+               `traffic` (HBM-side bytes) and `valu_insts_per_launch` from three rocprofv3
+               --pmc passes of this script spawned after the timed region (--pmc live, N = 1),
+               `bound` = "valu" when the VALU-issue time exceeds the HBM time
   kernels      every family's share of a step, from up to 3 untimed steps before the timed
                region with every launch bracketed (the timed region brackets the dominant
                family's launches only, unless --events all): the sum of its launches'
@@ -93,6 +96,63 @@ def algorithmic_bytes(kernel, n_rays, voxels, cfg, images=1, folded=False, stric
     return 0
 
 
+KERNEL_OF_FAMILY = {"sweep_map": "k_sweep_map", "bp": "k_bp", "scatter": "k_scatter_box",
+                    "depth": "k_depth", "traverse": "k_traverse"}
+
+
+def live_pmc(config, family, budget_s=240.0):
+    """HBM-side traffic and VALU instructions of the dominant kernel, per launch, measured NOW:
+    three rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU: each counter set in
+    its own run, kernel-trace only, as MI355X_MICROARCH.md prescribes) of this very script with
+    --steps 1, spawned from here.  -> dict or None (no rocprofv3, a pass failed, out of time)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    kernel = KERNEL_OF_FAMILY.get(family)
+    if not os.path.exists(rocprof) or kernel is None:
+        return None
+    out = {}
+    t_start = time.perf_counter()
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU"]):
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 20:
+            return None
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            cmd = [rocprof, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv",
+                                                  "-d", d, "-o", "p", "--", sys.executable,
+                                                  os.path.abspath(__file__), "--steps", "1",
+                                                  "--warmup", "1", "--no-cpu-baseline",
+                                                  "--pmc", "off", "--config", config]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=min(left, 120.0))
+            if r.returncode != 0:
+                return None
+            tot, n = {}, {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel in row.get("Kernel_Name", ""):
+                            c = row["Counter_Name"]
+                            tot[c] = tot.get(c, 0.0) + float(row["Counter_Value"])
+                            n[c] = n.get(c, 0) + 1
+            for c in counters:
+                if not n.get(c):
+                    return None
+                out[c] = tot[c] / n[c]
+                out["launches"] = n[c]
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out["seconds"] = time.perf_counter() - t_start
+    return out
+
+
 def timeline_shares(launches, starts):
     """launches: (family, n_rays, duration ms) per launch; starts: its start (ms, one clock).
     -> {family: ms}: an instant with k launches in flight gives each of them 1 / k of it.
@@ -128,6 +188,11 @@ def main():
                     help="launches bracketed by HIP events inside the timed region: those of the "
                          "dominant kernel family (the roofline block), or all of them")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--pmc", default="live", choices=["live", "table", "off"],
+                    help="roofline.traffic / valu_insts of the dominant kernel: measured now by "
+                         "rocprofv3 --pmc passes of this script spawned from this run (live; N = 1 "
+                         "only, falls back to the table), read from profiles/pmc_traffic.json "
+                         "(table), or left out (off)")
     args = ap.parse_args()
 
     import torch
@@ -265,7 +330,21 @@ def main():
         # this configuration, never measured inside this run -- traffic_source says so
         traffic = traffic_source = valu_insts = None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if world == 1 and os.path.exists(tpath):     # measured at N=1 launch sizes
+        live = None
+        if world == 1 and args.pmc == "live":
+            # frees the GPU's memory first: the profiled child builds its own 7 - 25 GB plan
+            fp._plan = None
+            torch.cuda.empty_cache()
+            live = live_pmc(args.config, dominant)
+        if live is not None:
+            # 2 x FETCH_SIZE + WRITE_SIZE, KiB: the gfx950 correction of MI355X_MICROARCH.md (HBM)
+            traffic = int((2 * live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024)
+            valu_insts = live["SQ_INSTS_VALU"]
+            traffic_source = ("measured in this run: three rocprofv3 --pmc passes (FETCH_SIZE, "
+                              "WRITE_SIZE, SQ_INSTS_VALU; kernel-trace only) of `bench.py --steps 1` "
+                              "spawned by this process, mean of %d launches, %.0f s" % (
+                                  live["launches"], live["seconds"]))
+        elif world == 1 and args.pmc != "off" and os.path.exists(tpath):   # N=1 launch sizes
             try:
                 tj = json.load(open(tpath)).get(args.config)
                 if tj is not None and dominant in tj["kernels"]:

@@ -14,7 +14,7 @@ cd $R
 python bench.py --steps 10 --warmup 2 $BARGS 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline $BARGS > $OUT/${TAG}_rocprof_bench_line.txt 2>/tmp/prof_kt.log
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --pmc table $BARGS > $OUT/${TAG}_rocprof_bench_line.txt 2>/tmp/prof_kt.log
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 if [ -n "$DB" ]; then python $R/tools/rocpd_summary.py $DB $OUT/${TAG}_kernel_stats_rocprofv3.txt > /dev/null; fi
 CSV=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1)
