@@ -100,7 +100,7 @@ KERNEL_OF_FAMILY = {"sweep_map": "k_sweep_map", "bp": "k_bp", "scatter": "k_scat
                     "depth": "k_depth", "traverse": "k_traverse"}
 
 
-def live_pmc(config, family, budget_s=240.0):
+def live_pmc(config, family, budget_s=150.0):
     """HBM-side traffic and VALU instructions of the dominant kernel, per launch, measured NOW:
     three rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU: each counter set in
     its own run, kernel-trace only, as MI355X_MICROARCH.md prescribes) of this very script with
@@ -129,7 +129,7 @@ def live_pmc(config, family, budget_s=240.0):
                                                   "--warmup", "1", "--no-cpu-baseline",
                                                   "--pmc", "off", "--config", config]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=min(left, 120.0))
+                               stderr=subprocess.DEVNULL, timeout=min(left, 60.0))
             if r.returncode != 0:
                 return None
             tot, n = {}, {}
