@@ -34,7 +34,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from .hip_implementations import get_context
 from .hip_implementations.options import PathOptions, shard_alpha_for
 from .hip_implementations.mvcnn_with_ray_marching_and_voxels_mapping import \
     batch_mvcnn_voxel_traversal_with_ray_marching_with_depth_estimation
