@@ -466,19 +466,20 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             const int k = min(base + lane, p.D - 1);
             float point[3];
             plane_point(s, e, k, p.D, point);
+            // The 12 entries of a view's matrix are wave-uniform: scalar loads into SGPRs, all
+            // NV x 12 of them hoisted out of the chunk loop -- beyond 6 views more than there
+            // are: 125 SGPRs spilled at 9 views, ~300 v_writelane / v_readlane in the kernel.
+            // Every way of not spilling them was measured SLOWER at config 4 (17.0 -> 18.5 - 20.5
+            // ms, with 11 % fewer VALU instructions): reloading a view's matrix where it is used
+            // (the pointer made opaque by an empty asm; -DRN_SWEEP_SGPR_VIEWS=n: from view n on),
+            // requesting it one view ahead, staging the matrices in LDS -- the reloads' latency,
+            // or the asm barriers between the views' projections, cost more than the spill code
+            // (profiles/r03_exp_view_matrix_sgprs.txt).
 #pragma unroll
             for (int v = 0; v < NV; v++) {
 #ifdef RN_EXP_SWEEP_NOPROJ      // timing experiment only (wrong results): no projection arithmetic
                 offb[v] = (int)(((unsigned)(k * 977 + v * 131071 + lane * 8191) * 128u) & 0xffffffu);
 #else
-                // The 12 entries of a view's matrix are wave-uniform: scalar loads into SGPRs,
-                // all NV x 12 of them hoisted out of the chunk loop -- beyond 6 views more than
-                // there are: 125 SGPRs spilled at 9 views, ~300 v_writelane / v_readlane in the
-                // kernel.  (Reloading a view's matrix where it is used -- the pointer made
-                // opaque by an empty asm, for all or only the last views -- removes every spill
-                // and is 11 % SLOWER at config 4, 17.3 -> 19.3 ms: the scalar loads' latency
-                // lands in front of every view's projection, -DRN_SWEEP_SGPR_VIEWS=n; the matrices
-                // from LDS into VGPRs: 19 % slower, 20.5 ms.  profiles/r03_exp_view_matrix_sgprs.txt)
                 const float *Pv = P + 12 * v;
                 if (v >= RN_SWEEP_SGPR_VIEWS) asm volatile("" : "+s"(Pv));
                 offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, Pv, point, pad_shift);
