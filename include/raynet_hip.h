@@ -360,11 +360,12 @@ typedef enum {
     RN_RUN_COMBINE = 4,   /* deterministic mode: acc[iteration & 1] = prior + acc_fixed            */
     RN_RUN_DEPTH = 8,     /* depth sweep of image `image` (all images in one launch if < 0) after
                              `iteration` BP iterations                                             */
-    RN_RUN_DEPTH_HEAD = 16 /* depth sweep of images [0, image) in ONE launch: a single GPU decodes
-                             all images but the last together (no launch tails between them) and
-                             the last one on its own, under which the others' maps leave        */
+    RN_RUN_DEPTH_RANGE = 16 /* depth sweep of `count` consecutive images from `first` in ONE launch,
+                             `image` = first | count << 16: a single GPU decodes all images but
+                             the last together (no launch tails between them) and the last one on
+                             its own, under which the others' maps leave                         */
 } rn_run_phase;
-/* Runs the phases named in `phases` in the order PREPARE, SWEEP, COMBINE, DEPTH_HEAD / DEPTH.
+/* Runs the phases named in `phases` in the order PREPARE, SWEEP, COMBINE, DEPTH_RANGE / DEPTH.
  * (The first PREPARE | SWEEP of iteration 0 with a given prior synchronises `stream` once: the one
  * occupancy of that iteration is evaluated on the device and kept with the context.) */
 int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *plan, int32_t phases, int32_t iteration,

@@ -73,7 +73,7 @@ class ScenePlan(ctypes.Structure):
     ]
 
 
-RN_RUN_PREPARE, RN_RUN_SWEEP, RN_RUN_COMBINE, RN_RUN_DEPTH, RN_RUN_DEPTH_HEAD = 1, 2, 4, 8, 16
+RN_RUN_PREPARE, RN_RUN_SWEEP, RN_RUN_COMBINE, RN_RUN_DEPTH, RN_RUN_DEPTH_RANGE = 1, 2, 4, 8, 16
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int32

@@ -1267,11 +1267,14 @@ int rn_scene_depth(rn_ctx *ctx, int32_t n, const float *Sr, const int32_t *vox,
 int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t iteration,
                  int32_t image, void *stream) {
     if (!ctx || !pl || pl->n_images < 1 || pl->n < 0 || pl->rows_per_image < pl->n ||
-        pl->rows_per_image % 256 || iteration < 0 || image >= pl->n_images ||
+        pl->rows_per_image % 256 || iteration < 0 ||
+        (!(phases & RN_RUN_DEPTH_RANGE) && image >= pl->n_images) ||
         (!pl->ray_idxs && pl->n) || !pl->features_views || !pl->cameras || !pl->vox || !pl->rvc || !pl->Sr || !pl->msgs ||
         !pl->acc[0] || !pl->acc[1] || !pl->depth ||
-        (phases & ~(RN_RUN_PREPARE | RN_RUN_SWEEP | RN_RUN_COMBINE | RN_RUN_DEPTH | RN_RUN_DEPTH_HEAD)) ||
-        ((phases & RN_RUN_DEPTH_HEAD) && (image < 1 || (phases & RN_RUN_DEPTH))))
+        (phases & ~(RN_RUN_PREPARE | RN_RUN_SWEEP | RN_RUN_COMBINE | RN_RUN_DEPTH | RN_RUN_DEPTH_RANGE)) ||
+        ((phases & RN_RUN_DEPTH_RANGE) &&
+         (image < 0 || (image >> 16) < 1 || (image & 0xffff) + (image >> 16) > pl->n_images ||
+          (phases & RN_RUN_DEPTH))))
         return fail(ctx, RN_ERR_INVALID, "rn_scene_run: bad plan or phase");
     int rc = need_axes(ctx);
     if (rc) return rc;
@@ -1323,7 +1326,7 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
         rc = rn_acc_combine_fixed(ctx, pl->acc_fixed, pl->prior, pl->acc[iteration & 1], stream);
         if (rc) return rc;
     }
-    if (phases & (RN_RUN_DEPTH | RN_RUN_DEPTH_HEAD)) {
+    if (phases & (RN_RUN_DEPTH | RN_RUN_DEPTH_RANGE)) {
         AccMode am;
         am.biased = !fixed;
         am.bias = pl->prior;
@@ -1331,10 +1334,18 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
         const int cam_stride = 12 * ctx->p.N + 12 + 4;
         const float *cc = pl->cameras + 12 * ctx->p.N + 12;
         const size_t M = (size_t)ctx->p.M;
-        if (image < 0 || (phases & RN_RUN_DEPTH_HEAD))
-            return launch_depth<true, false>(ctx, image < 0 ? (int)rows : (int)(image * pl->rows_per_image),
-                                             pl->Sr, pl->vox, pl->rvc, acc, pl->msgs, cc, nullptr,
-                                             pl->depth, st, (int)pl->rows_per_image, am, cam_stride);
+        if (image < 0)
+            return launch_depth<true, false>(ctx, (int)rows, pl->Sr, pl->vox, pl->rvc, acc, pl->msgs, cc,
+                                             nullptr, pl->depth, st, (int)pl->rows_per_image, am,
+                                             cam_stride);
+        if (phases & RN_RUN_DEPTH_RANGE) {
+            const int first = image & 0xffff, count = image >> 16;
+            const size_t r0 = (size_t)first * pl->rows_per_image;
+            return launch_depth<true, false>(ctx, (int)(count * pl->rows_per_image), pl->Sr + r0 * M,
+                                             pl->vox + r0 * M, pl->rvc + r0, acc, pl->msgs + r0 * M,
+                                             cc + (size_t)first * cam_stride, nullptr, pl->depth + r0,
+                                             st, (int)pl->rows_per_image, am, cam_stride);
+        }
         const size_t row0 = (size_t)image * pl->rows_per_image;
         return launch_depth<true, false>(ctx, pl->n, pl->Sr + row0 * M, pl->vox + row0 * M,
                                          pl->rvc + row0, acc, pl->msgs + row0 * M,

@@ -771,10 +771,13 @@ class RayNetForwardPass(ForwardPass):
         V = len(refs)
         if dist is None and V >= 3 and self.options.depth_head:
             # one GPU: all images but the last decoded by ONE launch (no launch tails between
-            # them), the last on its own -- long enough for the others' maps to leave under it
-            ctx.scene_run(fast, _lib.RN_RUN_DEPTH_HEAD, T, V - 1)
-            for k in range(V - 1):
-                self._emit_image(plan, k, per_image[refs[k]], dist, world, slot)
+            # them), the last on its own -- long enough for the others' maps to leave under it.
+            # (A rank of several keeps one launch per image: pairs were measured slower there,
+            # 1.23 - 1.29 -> 1.26 - 1.32 ms per step of an eight-rank shard -- its tail is the
+            # exchange and copy of whatever the last launch covers.)
+            ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, 0 | ((V - 1) << 16))
+            for j in range(V - 1):
+                self._emit_image(plan, j, per_image[refs[j]], dist, world, slot)
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, V - 1)
             self._emit_image(plan, V - 1, per_image[refs[V - 1]], dist, world, slot)
             return slot
