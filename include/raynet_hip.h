@@ -353,6 +353,13 @@ typedef struct {
     float *depth;                  /* [n_images*rows_per_image]                          */
     float prior;                   /* log(gamma / (1 - gamma)), forward_pass.py:533-538  */
     int32_t row_layout;            /* rn_row_layout                                      */
+    float *depth_image;            /* optional [n_images][depth_image_stride]: the depth sweeps
+                                      write image g's map in RAY-INDEX (pixel) order,
+                                      depth_image[g*stride + ray_idxs[row]], instead of depth[]
+                                      in row order -- what forward_pass.py:744 hands out, with
+                                      no reordering pass behind the sweep.  Entries no ray of the
+                                      list maps to are left as they are                      */
+    int64_t depth_image_stride;    /* floats between two images' maps (>= max ray index + 1) */
 } rn_scene_plan;
 typedef enum {
     RN_RUN_PREPARE = 1,   /* traversal + plane sweep + mapping of all images (rn_scene_prepare_all) */

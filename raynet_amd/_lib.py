@@ -70,6 +70,7 @@ class ScenePlan(ctypes.Structure):
         ("msgs", ctypes.c_void_p), ("ray_segments", ctypes.c_void_p),
         ("acc", ctypes.c_void_p * 2), ("acc_fixed", ctypes.c_void_p),
         ("depth", ctypes.c_void_p), ("prior", ctypes.c_float), ("row_layout", ctypes.c_int32),
+        ("depth_image", ctypes.c_void_p), ("depth_image_stride", ctypes.c_int64),
     ]
 
 

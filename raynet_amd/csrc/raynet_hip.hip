@@ -561,13 +561,14 @@ template <bool PACKED, bool CLIP_IN>
 int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int32_t *rvc,
                  const float *acc, const float *msgs, const float *cc, float *S_new,
                  float *depth_map, hipStream_t st, int rays_per_center = 0,
-                 const AccMode &am = AccMode(), int cc_stride = 4) {
+                 const AccMode &am = AccMode(), int cc_stride = 4,
+                 const DepthDest &dest = DepthDest()) {
     const int nch = (ctx->p.M + WAVE - 1) / WAVE;
     ProfScope prof(ctx, RN_K_DEPTH, n, st);
 #define RN_DE(NCH_)                                                                             \
     hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN>), dim3(ray_blocks_mrf(n)), dim3(RN_RAY_BLOCK), 0, st, \
                        ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, S_new, depth_map,           \
-                       rays_per_center, am.bias, am.biased ? 1 : 0, cc_stride)
+                       rays_per_center, am.bias, am.biased ? 1 : 0, cc_stride, dest)
     if (nch <= 2) RN_DE(2);
     else if (nch <= 4) RN_DE(4);
     else if (nch <= 6) RN_DE(6);
@@ -1271,6 +1272,7 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
         (!(phases & RN_RUN_DEPTH_RANGE) && image >= pl->n_images) ||
         (!pl->ray_idxs && pl->n) || !pl->features_views || !pl->cameras || !pl->vox || !pl->rvc || !pl->Sr || !pl->msgs ||
         !pl->acc[0] || !pl->acc[1] || !pl->depth ||
+        (pl->depth_image && pl->depth_image_stride < 1) ||
         (phases & ~(RN_RUN_PREPARE | RN_RUN_SWEEP | RN_RUN_COMBINE | RN_RUN_DEPTH | RN_RUN_DEPTH_RANGE)) ||
         ((phases & RN_RUN_DEPTH_RANGE) &&
          (image < 0 || (image >> 16) < 1 || (image & 0xffff) + (image >> 16) > pl->n_images ||
@@ -1334,23 +1336,35 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
         const int cam_stride = 12 * ctx->p.N + 12 + 4;
         const float *cc = pl->cameras + 12 * ctx->p.N + 12;
         const size_t M = (size_t)ctx->p.M;
+        // depth_image: the maps leave in pixel order (no reordering pass behind the sweep)
+        DepthDest dest;
+        if (pl->depth_image) {
+            dest.pixel_of_row = pl->ray_idxs;
+            dest.rows = pl->n;
+            dest.image_stride = pl->depth_image_stride;
+        }
+        auto out = [&](int first) {
+            return pl->depth_image ? pl->depth_image + (size_t)first * pl->depth_image_stride
+                                   : pl->depth + (size_t)first * pl->rows_per_image;
+        };
         if (image < 0)
             return launch_depth<true, false>(ctx, (int)rows, pl->Sr, pl->vox, pl->rvc, acc, pl->msgs, cc,
-                                             nullptr, pl->depth, st, (int)pl->rows_per_image, am,
-                                             cam_stride);
+                                             nullptr, out(0), st, (int)pl->rows_per_image, am,
+                                             cam_stride, dest);
         if (phases & RN_RUN_DEPTH_RANGE) {
             const int first = image & 0xffff, count = image >> 16;
             const size_t r0 = (size_t)first * pl->rows_per_image;
             return launch_depth<true, false>(ctx, (int)(count * pl->rows_per_image), pl->Sr + r0 * M,
                                              pl->vox + r0 * M, pl->rvc + r0, acc, pl->msgs + r0 * M,
-                                             cc + (size_t)first * cam_stride, nullptr, pl->depth + r0,
-                                             st, (int)pl->rows_per_image, am, cam_stride);
+                                             cc + (size_t)first * cam_stride, nullptr, out(first),
+                                             st, (int)pl->rows_per_image, am, cam_stride, dest);
         }
         const size_t row0 = (size_t)image * pl->rows_per_image;
+        // (one image: a single group of rows_per_image >= n rows)
         return launch_depth<true, false>(ctx, pl->n, pl->Sr + row0 * M, pl->vox + row0 * M,
                                          pl->rvc + row0, acc, pl->msgs + row0 * M,
-                                         cc + (size_t)image * cam_stride, nullptr, pl->depth + row0,
-                                         st, 0, am);
+                                         cc + (size_t)image * cam_stride, nullptr, out(image),
+                                         st, 0, am, 4, dest);
     }
     return RN_OK;
 }

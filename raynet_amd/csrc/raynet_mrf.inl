@@ -945,6 +945,14 @@ __device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int
     }
 }
 
+// where a ray's depth goes: depth_map[row] (pixel_of_row == nullptr) or, per group of
+// rays_per_center rows (one reference image), depth_map[group * image_stride + pixel_of_row[row
+// within the group]] for the group's first `rows` rows (the rest are padding)
+struct DepthDest {
+    const int32_t *pixel_of_row = nullptr;
+    int rows = 0;
+    int64_t image_stride = 0;
+};
 template <int NCH, bool PACKED, bool CLIP_IN>
 __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const float *S,
                                                  const int32_t *__restrict__ vox,
@@ -954,11 +962,21 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const f
                                                  const float *__restrict__ axes,
                                                  const float *__restrict__ cc, float *S_new,
                                                  float *depth_map, int rays_per_center,
-                                                 float acc_bias, int biased, int cc_stride) {
+                                                 float acc_bias, int biased, int cc_stride,
+                                                 DepthDest dest) {
     int lane;
     const int r = ray_of_wave<RN_RAY_BLOCK, RN_XCD_CHUNK_DEPTH>(n, lane);
     if (r < 0) return;
-    if (rays_per_center > 0 && cc) cc += (size_t)cc_stride * (r / rays_per_center);
+    const int group = rays_per_center > 0 ? r / rays_per_center : 0;
+    if (rays_per_center > 0 && cc) cc += (size_t)cc_stride * group;
+    // where the depth goes: fetched HERE (a scalar load under the row loads), not behind the
+    // arg-max -- a dependent round trip at the end of every wavefront's life costs the launch 3 %
+    int64_t out_at = r;
+    if (dest.pixel_of_row) {
+        const int lr = r - group * rays_per_center;
+        out_at = lr < dest.rows
+                     ? (int64_t)group * dest.image_stride + uniform(dest.pixel_of_row[lr]) : -1;
+    }
     const int count = min(uniform(rvc[r]), p.M);
     float best = -INFINITY;
     int best_i = 0;
@@ -994,7 +1012,9 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const f
             const float d = pt[i] - cc[i];
             sum += d * d;
         }
-        depth_map[r] = sqrtf(sum);
+        // row order, or the map in PIXEL order (forward_pass.py:744 hands out `.reshape(W, H).T`
+        // of the ray-index-ordered vector): no reordering pass behind the sweep
+        if (out_at >= 0) depth_map[out_at] = sqrtf(sum);
     }
 }
 

@@ -607,7 +607,7 @@ class RayNetForwardPass(ForwardPass):
         plan = dict(key=key, ptrs=ptrs, scene=scene, cams=cams, prior=self._prior(), dirty=False,
                     cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
                     balance=balance, shards=shards, npad=npad, shared=shared,
-                    patch_rows=patch_rows, orders={}, stitch=None, fast=None, slot=0,
+                    patch_rows=patch_rows, orders={}, stitch=None, fast=None, slot=0, direct=False,
                     table=torch.tensor(ptrs, dtype=torch.int64).to(dev) if V else None)
         self._plan_buffers(ctx, plan, refs, old_bytes)
         # static views of every image's rows in the scene-wide buffers
@@ -642,11 +642,17 @@ class RayNetForwardPass(ForwardPass):
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             fast_ok = bool(int(t.item()))
         if fast_ok:
+            # no process group: the depth sweeps write the maps in pixel order themselves
+            # (rn_scene_plan.depth_image) -- no reordering pass between sweep and copy.  (With
+            # a group the rows are exchanged first, _emit_image.)
+            plan["direct"] = dist is None and dev.type == "cuda" and opt.direct_maps
+            if plan["direct"]:
+                plan["maps_dev"] = torch.zeros((V, H * W), dtype=torch.float32, device=dev)
             plan["fast"] = ctx.scene_plan(
                 V, npad, shards[0][0], plan["table"], cam_dev, plan["vox"], plan["rvc"],
                 plan["Sr"], plan["msgs"], plan["acc_a"], plan["acc_b"], plan["depth"],
                 plan["prior"], patch_rows, acc_fixed=plan["acc_part"] if plan["fixed"] else None,
-                order=order)
+                order=order, **({"depth_image": plan["maps_dev"]} if plan["direct"] else {}))
         if not self._filter_out_rays:
             self._plan = plan
         return plan
@@ -664,7 +670,9 @@ class RayNetForwardPass(ForwardPass):
         V, HW = len(refs), H * W
         plan["host"] = [torch.empty((V, HW), dtype=torch.float32, pin_memory=cuda) for _ in range(2)]
         plan["host_np"] = [[h[k].numpy().reshape(W, H).T for k in range(V)] for h in plan["host"]]
-        plan["maps_dev"] = torch.zeros((V, HW), dtype=torch.float32, device=dev)
+        if "maps_dev" not in plan:
+            plan["maps_dev"] = torch.zeros((V, HW), dtype=torch.float32, device=dev)
+        plan["wait_ev"] = [None] * V
         if cuda:
             plan["ev_ready"] = [torch.cuda.Event() for _ in range(V)]
             plan["ev_stitch"] = [torch.cuda.Event() for _ in range(V)]
@@ -719,6 +727,19 @@ class RayNetForwardPass(ForwardPass):
             copy.wait_event(plan["ev_stitch"][k])
             host.copy_(src, non_blocking=True)
             plan["ev_done"][k].record()
+        plan["wait_ev"][k] = plan["ev_done"][k]
+
+    def _emit_direct(self, plan, groups, slot):
+        """The maps of the image groups [a, b) -- written in pixel order by their depth launches,
+        ev_ready[a] recorded behind each -- go to the pinned host maps, one copy per group."""
+        copy = self._copy_stream
+        with torch.cuda.stream(copy):
+            for a, b in groups:
+                copy.wait_event(plan["ev_ready"][a])
+                plan["host"][slot][a:b].copy_(plan["maps_dev"][a:b], non_blocking=True)
+                plan["ev_done"][a].record()
+                for k in range(a, b):
+                    plan["wait_ev"][k] = plan["ev_done"][a]
 
     def _exchange(self, plan, ctx, dist, world, it):
         """The ranks' partial sums of BP iteration `it` become everybody's accumulator: ONE
@@ -769,6 +790,19 @@ class RayNetForwardPass(ForwardPass):
         slot = plan["slot"] = plan["slot"] ^ 1
         per_image = plan["per_image"]
         V = len(refs)
+        if plan["direct"]:
+            # every depth launch first (the GPU never waits for the host between them), then
+            # the copies: all images but the last in ONE launch and ONE copy, under the last's
+            head = V >= 3 and self.options.depth_head
+            groups = [(0, V - 1), (V - 1, V)] if head else [(k, k + 1) for k in range(V)]
+            for a, b in groups:
+                if b - a > 1:
+                    ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, a | ((b - a) << 16))
+                else:
+                    ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, a)
+                plan["ev_ready"][a].record()
+            self._emit_direct(plan, groups, slot)
+            return slot
         if dist is None and V >= 3 and self.options.depth_head:
             # one GPU: all images but the last decoded by ONE launch (no launch tails between
             # them), the last on its own -- long enough for the others' maps to leave under it.
@@ -835,7 +869,7 @@ class RayNetForwardPass(ForwardPass):
             maps = plan["host_np"][slot]
             spin = self.options.spin_wait
             for k, r in enumerate(refs):
-                ev = plan["ev_done"][k]
+                ev = plan["wait_ev"][k]
                 if spin:
                     while not ev.query():
                         pass

@@ -442,9 +442,11 @@ class HipContext(object):
             _ptr(self._segments(rows)), _stream()))
 
     def scene_plan(self, n_images, rows_per_image, ray_idxs, feature_table, cameras, vox, rvc, Sr,
-                   msgs, acc0, acc1, depth, prior, patch_rows, acc_fixed=None, order=None):
+                   msgs, acc0, acc1, depth, prior, patch_rows, acc_fixed=None, order=None,
+                   depth_image=None):
         """An rn_scene_plan over the caller's buffers, every tensor validated ONCE here; the
-        returned object (which keeps them alive) goes to scene_run."""
+        returned object (which keeps them alive) goes to scene_run.  depth_image [n_images, R]:
+        the depth sweeps write the maps in ray-index (pixel) order there instead of `depth`."""
         n, rows = len(ray_idxs), int(n_images) * int(rows_per_image)
         f32, i32, ra = torch.float32, torch.int32, self._row_align
         assert rows_per_image % 256 == 0 and n <= rows_per_image
@@ -470,8 +472,16 @@ class HipContext(object):
         pl.acc_fixed = acc_fixed.data_ptr() if acc_fixed is not None else None
         pl.depth, pl.prior = depth.data_ptr(), float(prior)
         pl.row_layout = 1 if patch_rows else 0
+        pl.depth_image, pl.depth_image_stride = None, 0
+        if depth_image is not None:
+            assert depth_image.dim() == 2 and depth_image.shape[0] == n_images
+            _chk(depth_image, f32, depth_image.numel(), "depth_image")
+            if n:       # every ray index is a valid entry of an image's map (checked once, here)
+                lo, hi = int(ray_idxs.min()), int(ray_idxs.max())
+                assert 0 <= lo and hi < depth_image.shape[1], (lo, hi, tuple(depth_image.shape))
+            pl.depth_image, pl.depth_image_stride = depth_image.data_ptr(), int(depth_image.shape[1])
         pl._keepalive = (ray_idxs, feature_table, cameras, vox, rvc, Sr, msgs, acc0, acc1, depth,
-                         acc_fixed, order, seg)
+                         acc_fixed, order, seg, depth_image)
         pl._ref = ctypes.byref(pl)
         return pl
 

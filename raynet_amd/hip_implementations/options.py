@@ -37,6 +37,7 @@ class PathOptions:
     slab_boxes: bool = True           # the scatters merge the traversal's slab boxes instead of scanning
     plan_path: bool = True            # one C call per phase of a pass (rn_scene_run) when the pass qualifies
     depth_head: bool = True           # one GPU: all images but the last decoded by one launch
+    direct_maps: bool = True          # no process group: the depth sweeps write pixel-order maps
     spin_wait: bool = False           # poll the maps' events instead of blocking on them
     # ---- memory ---------------------------------------------------------------------------
     resident_gb: float = 0.0          # HBM budget of the resident schedule; 0: 90 % of what is free
@@ -62,6 +63,7 @@ class PathOptions:
         "RAYNET_SLAB_BOXES": ("slab_boxes", _flag),
         "RAYNET_PLAN_PATH": ("plan_path", _flag),
         "RAYNET_DEPTH_HEAD": ("depth_head", _flag),
+        "RAYNET_DIRECT_MAPS": ("direct_maps", _flag),
         "RAYNET_SPIN_WAIT": ("spin_wait", _flag),
         "RAYNET_RESIDENT_GB": ("resident_gb", float),
         "RAYNET_DETERMINISTIC": ("deterministic", _flag),

@@ -368,6 +368,33 @@ def test_plan_path_equals_the_launch_by_launch_path(torch):
         assert np.abs(res[True, False][1] - res[True, True][1]).max() <= 5e-4
 
 
+def test_pixel_order_maps_straight_from_the_depth_sweep(torch):
+    """Without a process group the depth launches write the maps in ray-index (pixel) order
+    themselves (rn_scene_plan.depth_image) and a group of images leaves in one copy: the same
+    bits as the row-order maps re-ordered behind the sweep (direct_maps=False), for image counts
+    with and without the head launch, rows that do not fill their last tile (45 x 61 rays),
+    ray-index rows, and a sub-range of the images."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.hip_implementations.options import PathOptions
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W = 45, 61
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(32, 192, (64, 64, 64))
+    cls = get_forward_pass_factory("raynet")
+    for rng, tile in (((0, 5, 1), (16, 16)), ((0, 2, 1), (16, 16)), ((1, 5, 2), None), ((0, 5, 1), None)):
+        out = {}
+        for direct in (True, False):
+            fp = cls(bank, gp, "sample_in_bbox", (H, W), 0,
+                     options=PathOptions(deterministic=True, direct_maps=direct, ray_tile=tile))
+            out[direct] = np.stack([m.copy() for m in fp.forward_pass(scene, rng)])
+            assert fp._plan["fast"] is not None and fp._plan["direct"] == direct
+            again = np.stack(list(fp.forward_pass(scene, rng)))         # the other host slot
+            assert np.array_equal(again, out[direct])
+        assert out[True].shape == (len(range(*rng)), H, W)
+        assert np.array_equal(out[True], out[False]), (rng, tile)
+        assert out[True].min() > 0
+
+
 def test_plan_is_keyed_on_geometry_and_refreshed_for_moved_features(torch):
     """The plan of a pass is reused while cameras, neighbour selection, image range, shapes and
     options stay the same; feature maps that moved (recomputed into new allocations) only refresh
