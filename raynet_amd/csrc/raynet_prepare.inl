@@ -130,9 +130,61 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
     int cx = cur[0], cy = cur[1], cz = cur[2];
     float tx = tm[0], ty = tm[1], tz = tm[2];
     int count = 0;           // voxels emitted so far by this ray
+#if !defined(RN_TRAV_BRANCHES) && !defined(RN_TRAV_COORDS)
+    // The walk on the PACKED voxel word: a step adds +-1 to one 10-bit field (a field that
+    // leaves [0, g) may borrow from / carry into its neighbour -- the ray is switched off in
+    // that very step and the word never emitted), the end test is one comparison of words,
+    // and leaving the grid is the sign of a per-axis count of the steps that are left
+    // (decremented by the step's own mask: subtract-with-borrow, no select).  Same choices,
+    // same additions on tx / ty / tz, same list: 29 -> 20 vector instructions per step.
+    int pk = pack_voxel(cx, cy, cz);
+    const bool last_in = (unsigned)last[0] < (unsigned)g[0] && (unsigned)last[1] < (unsigned)g[1] &&
+                         (unsigned)last[2] < (unsigned)g[2];
+    const int pk_last = last_in ? pack_voxel(last[0], last[1], last[2]) : -1;   // -1: no voxel's word
+    const int ux = step[0] * (1 << 20), uy = step[1] * (1 << 10), uz = step[2];
+    int room_x = step[0] > 0 ? g[0] - 1 - cx : cx, room_y = step[1] > 0 ? g[1] - 1 - cy : cy,
+        room_z = step[2] > 0 ? g[2] - 1 - cz : cz;
+#endif
     // `active` = this ray still has a voxel (cx,cy,cz) to emit at index `count`
+#if !defined(RN_TRAV_BRANCHES) && !defined(RN_TRAV_COORDS)
+    // one step of an active ray: emit, then advance (ray_tracing.pyx:166-197).  Everything is
+    // computed unconditionally and the ray switched off at the end -- a ray that has just
+    // emitted its last voxel moves once more into a word nobody reads.  `count >= M` is the
+    // loops' own bound (every active ray has emitted base + k + 1 voxels); the count itself
+    // is read off the counters once per tile.
+#define RN_DDA_STEP(k)                                                             \
+    if (active) {                                                                  \
+        if (vox) tile[lane * (TRAV_TILE + 1) + (k)] = pk;                          \
+        const bool at_last = pk == pk_last;                                        \
+        const bool a_ = tx < ty, b_ = tx < tz, c_ = ty < tz;                       \
+        const bool mx = a_ & b_, my = !a_ & c_, mxy = mx | my; /* mz = !mxy */     \
+        const int uyz = my ? uy : uz;                                              \
+        pk += mx ? ux : uyz;                                                       \
+        tx += mx ? td0 : 0.0f;                                                     \
+        ty += my ? td1 : 0.0f;                                                     \
+        tz += mxy ? 0.0f : td2;                                                    \
+        room_x -= (int)mx;                                                         \
+        room_y -= (int)my;                                                         \
+        room_z = room_z - 1 + (int)mxy;                                            \
+        active = !at_last && (room_x | room_y | room_z) >= 0;                      \
+    }
+    const float td0 = td[0], td1 = td[1], td2 = td[2];
+    // every emitted voxel is followed by one move (also the last one, and the move that leaves
+    // the grid): voxels emitted = moves made = what the three counters have lost
+    const int room_sum0 = room_x + room_y + room_z;
+    const bool whole_tiles = p.M % TRAV_TILE == 0;
+#endif
     for (int base = 0; base < p.M; base += TRAV_TILE) {
         if (__ballot(active) == 0) break;
+#if !defined(RN_TRAV_BRANCHES) && !defined(RN_TRAV_COORDS)
+        if (whole_tiles) {
+#pragma unroll
+            for (int k = 0; k < TRAV_TILE; k++) { RN_DDA_STEP(k) }
+        } else {
+            for (int k = 0; k < TRAV_TILE && base + k < p.M; k++) { RN_DDA_STEP(k) }
+        }
+        count = room_sum0 - (room_x + room_y + room_z);
+#else
         for (int k = 0; k < TRAV_TILE && base + k < p.M; k++) {
             if (active) {
                 if (vox) tile[lane * (TRAV_TILE + 1) + k] = pack_voxel(cx, cy, cz);
@@ -183,6 +235,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
 #endif
             }
         }
+#endif
         if (!vox) continue;          // count-only launch (rn_scene_count_voxels): nothing to flush
         wave_sync();
         // Bounding box of the voxels these 64 rays emitted in this slab of steps, for the
