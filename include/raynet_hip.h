@@ -378,6 +378,14 @@ typedef enum {
 int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *plan, int32_t phases, int32_t iteration,
                  int32_t image, void *stream);
 
+/* out[i] = rows[index[i]] for i < n: the depth rows of a pass (one rank's, or the ranks' blocks
+ * side by side after the all-gather) into the ray-index order forward_pass.py:744 hands out.
+ * `out` (16-byte aligned, like `index`) may be PAGE-LOCKED HOST memory (hipHostMalloc, torch's
+ * pin_memory): the kernel then writes the map across PCIe itself -- the reordering pass and the
+ * device-to-host copy (`.get()`, forward_pass.py:739-744) are one launch on `stream`. */
+int rn_stitch_rows(rn_ctx *ctx, int64_t n, const float *rows, const int32_t *index, float *out,
+                   void *stream);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Per-launch hipEvent timing on the stream each kernel runs on.  Between
  * rn_prof_begin and rn_prof_end every kernel launch made through this context

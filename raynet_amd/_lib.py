@@ -118,6 +118,7 @@ SIGNATURES = {
                          ctypes.POINTER(ctypes.c_uint32)],
     "rn_acc_size": [_P],
     "rn_acc_to_grid": [_P, _P, _P, _P],
+    "rn_stitch_rows": [_P, _L, _P, _P, _P, _P],
     "rn_acc_from_grid": [_P, _P, _P, _P],
     "rn_scene_bp_sweep": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "rn_scene_bp_sweep_fixed": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],

@@ -200,6 +200,21 @@ __global__ void k_acc_regrid(Params p, const float *__restrict__ src, float *dst
         else dst[b] = src[i];
     }
 }
+// out[i] = rows[index[i]]: four entries per thread, one 16-byte store -- `out` may be page-locked
+// host memory, and whole 256-byte segments per wavefront are what a PCIe write wants
+__global__ void k_stitch_rows(int64_t n, const float *__restrict__ rows,
+                              const int32_t *__restrict__ index, float *out) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int4 ix = reinterpret_cast<const int4 *>(index)[i];
+        reinterpret_cast<float4 *>(out)[i] = make_float4(rows[ix.x], rows[ix.y], rows[ix.z], rows[ix.w]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        out[i] = rows[index[i]];
+    }
+}
 __global__ void k_add_scalar(float *a, int64_t n, float v) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
@@ -980,6 +995,31 @@ int rn_acc_to_grid(rn_ctx *ctx, const float *acc, float *grid_out, void *stream)
     const int64_t G = (int64_t)ctx->p.gx * ctx->p.gy * ctx->p.gz;
     hipLaunchKernelGGL((k_acc_regrid<true>), dim3(fill_blocks(G)), dim3(BLOCK), 0, S(stream),
                        ctx->p, acc, grid_out);
+    RN_LAUNCH_CHECK(ctx);
+    return RN_OK;
+}
+
+int rn_stitch_rows(rn_ctx *ctx, int64_t n, const float *rows, const int32_t *index, float *out,
+                   void *stream) {
+    if (!ctx || n < 0 || (n && (!rows || !index || !out)) || ((uintptr_t)out & 15) ||
+        ((uintptr_t)index & 15))
+        return fail(ctx, RN_ERR_INVALID, "rn_stitch_rows: bad argument");
+    if (n == 0) return RN_OK;
+    // page-locked host memory: the kernel writes through its device-side address
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeHost) {
+        if (!at.devicePointer)
+            return fail(ctx, RN_ERR_INVALID, "rn_stitch_rows: host memory that is not mapped");
+        out = static_cast<float *>(at.devicePointer);
+    } else {
+        (void)hipGetLastError();       // (an unregistered pointer: reported by the launch)
+    }
+    // 64 workgroups keep a PCIe link busy (16: 3 % slower per step of an eight-rank shard); one
+    // per CU only takes issue slots from the depth sweep this launch runs under (300: 1.5 %)
+    int nb = fill_blocks((n + 3) / 4);
+    if (nb > 64) nb = 64;
+    hipLaunchKernelGGL(k_stitch_rows, dim3(nb), dim3(BLOCK), 0, S(stream), n,
+                       rows, index, out);
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
 }

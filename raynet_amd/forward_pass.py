@@ -699,6 +699,8 @@ class RayNetForwardPass(ForwardPass):
                                                                    device=dev)
                 stitch.append(src)
             plan["stitch"] = stitch
+            # (rn_stitch_rows: the same table as 32-bit indices -- stitch and copy in one launch)
+            plan["stitch32"] = [t.to(torch.int32) for t in stitch] if cuda else None
 
     def _emit_image(self, plan, k, st, dist, world, slot):
         """Image k's depth rows (just enqueued on the current stream) -> pixel order -> pinned
@@ -715,6 +717,14 @@ class RayNetForwardPass(ForwardPass):
             if dist is not None:
                 g = plan["gathered"][k]
                 dist.all_gather_into_tensor(g[:-1], rows)
+                if plan.get("stitch32") is not None and hasattr(self._ctx, "stitch_rows") and \
+                        host.data_ptr() % 16 == 0:
+                    # pixel order AND the way to the host in one launch: the kernel writes the
+                    # pinned map itself (no second stream, no event hop, no copy)
+                    self._ctx.stitch_rows(g, plan["stitch32"][k], host)
+                    plan["ev_done"][k].record()
+                    plan["wait_ev"][k] = plan["ev_done"][k]
+                    return
                 torch.index_select(g, 0, plan["stitch"][k], out=plan["maps_dev"][k])
                 src = plan["maps_dev"][k]
             elif plan["pix"] is not None:

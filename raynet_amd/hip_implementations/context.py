@@ -191,6 +191,22 @@ class HipContext(object):
         self._check(self.lib.rn_acc_to_grid(self._h, _ptr(acc), _ptr(out), _stream()))
         return out
 
+    def stitch_rows(self, rows, index, out):
+        """out[i] = rows[index[i]] (rn_stitch_rows) on the current stream; `out` is a CUDA tensor
+        or a PINNED host tensor -- the kernel then writes the map across PCIe itself.  The
+        caller vouches for index < rows.numel() (a plan checks its tables once)."""
+        n = int(index.numel())
+        _chk(rows, torch.float32, 1 if n else 0, "rows")
+        _chk(index, torch.int32, n, "index", align=16)
+        if not (isinstance(out, torch.Tensor) and out.dtype == torch.float32 and
+                out.is_contiguous() and out.numel() >= n and (out.is_cuda or out.is_pinned()) and
+                (n == 0 or out.data_ptr() % 16 == 0)):
+            raise ValueError("out: expected a contiguous float32 CUDA or pinned tensor of >= %d "
+                             "elements, 16-byte aligned" % n)
+        self._check(self.lib.rn_stitch_rows(self._h, n, _ptr(rows), _ptr(index), out.data_ptr(),
+                                            _stream()))
+        return out
+
     def acc_from_grid(self, grid):
         grid = self.dev(grid, torch.float32).contiguous()
         out = torch.zeros((self.acc_size(),), dtype=torch.float32, device=grid.device)

@@ -889,6 +889,36 @@ def test_exact_arithmetic_shortcuts(torch, oracle_mod):
     assert np.array_equal(out[0][fin], expect.astype(np.float32)[fin])
 
 
+def test_stitch_rows_into_device_and_pinned_host_memory(torch, oracle_mod):
+    """rn_stitch_rows: out[i] = rows[index[i]] -- the ranks' gathered depth rows into pixel order,
+    written by the kernel into a CUDA tensor or straight into page-locked HOST memory (stitch and
+    device-to-host copy in one launch); lengths that are not multiples of 4, an empty call,
+    and the argument checks."""
+    o, _, _ = make_case(oracle_mod, CU["small"])
+    ctx = hip_ctx(o)
+    rng = np.random.default_rng(11)
+    for n, m in ((307200, 8 * 38912 + 1), (2745, 3001), (4, 4), (3, 9), (0, 5)):
+        rows = torch.from_numpy(rng.standard_normal(m).astype(np.float32)).cuda()
+        index = torch.from_numpy(rng.integers(0, m, n).astype(np.int32)).cuda()
+        want = rows[index.long()].cpu().numpy()
+        dev = torch.full((n + 8,), -7.0, device="cuda")
+        ctx.stitch_rows(rows, index, dev)
+        got = dev.cpu().numpy()
+        assert np.array_equal(got[:n], want) and np.all(got[n:] == -7.0)
+        host = torch.full((n + 8,), -7.0).pin_memory()
+        ctx.stitch_rows(rows, index, host)
+        torch.cuda.synchronize()
+        assert np.array_equal(host.numpy()[:n], want) and np.all(host.numpy()[n:] == -7.0)
+    rows = torch.zeros(16, device="cuda")
+    index = torch.zeros(8, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        ctx.stitch_rows(rows, index, torch.zeros(8))                     # pageable host memory
+    with pytest.raises(ValueError):
+        ctx.stitch_rows(rows, index, torch.zeros(16, device="cuda")[1:])  # not 16-byte aligned
+    with pytest.raises(ValueError):
+        ctx.stitch_rows(rows, index.long(), torch.zeros(8, device="cuda"))
+
+
 @pytest.mark.parametrize("D", [2, 3, 16, 64, 128, 1000, 4096])
 def test_mapping_shortcuts_are_exact(torch, D):
     """The resident path's planes -> voxels mapping replaces (a) the division by |ray|^2 with
