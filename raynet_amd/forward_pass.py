@@ -701,6 +701,25 @@ class RayNetForwardPass(ForwardPass):
             plan["stitch"] = stitch
             # (rn_stitch_rows: the same table as 32-bit indices -- stitch and copy in one launch)
             plan["stitch32"] = [t.to(torch.int32) for t in stitch] if cuda else None
+            # groups of images that share ONE depth launch, ONE all-gather and ONE stitch launch
+            # (a group's rows are contiguous in the scene-wide buffers, its host maps too)
+            gsz = self.options.rank_group
+            plan["rank_groups"] = None
+            if cuda and gsz > 0 and HW % 4 == 0 and hasattr(self._ctx, "stitch_rows") and \
+                    plan["fast"] is not None:
+                groups = [(a, min(a + gsz, V)) for a in range(0, V, gsz)]
+                gathered, tables = [], []
+                for a, b in groups:
+                    blk = (b - a) * npad                      # one rank's rows of the group
+                    gathered.append(torch.zeros((world * blk + 1,), dtype=torch.float32, device=dev))
+                    idx = torch.empty(((b - a), HW), dtype=torch.int32, device=dev)
+                    for k in range(a, b):
+                        q, j = stitch[k] // npad, stitch[k] % npad        # (rank, row) per pixel
+                        at = q * blk + (k - a) * npad + j
+                        idx[k - a] = torch.where(stitch[k] == world * npad,
+                                                 torch.full_like(at, world * blk), at).to(torch.int32)
+                    tables.append(idx.reshape(-1))
+                plan["rank_groups"], plan["gathered_grp"], plan["stitch32_grp"] = groups, gathered, tables
 
     def _emit_image(self, plan, k, st, dist, world, slot):
         """Image k's depth rows (just enqueued on the current stream) -> pixel order -> pinned
@@ -812,6 +831,35 @@ class RayNetForwardPass(ForwardPass):
                     ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, a)
                 plan["ev_ready"][a].record()
             self._emit_direct(plan, groups, slot)
+            return slot
+        if dist is not None and plan.get("rank_groups"):
+            # a rank of several: every group of images is ONE depth launch (all of them enqueued
+            # first: the GPU never waits for the host between them), then per group ONE
+            # all-gather of the ranks' row blocks and ONE rn_stitch_rows launch that puts them
+            # into pixel order and writes the pinned host maps across PCIe itself -- on the two
+            # side streams in turns, so that a group's exchange does not queue behind the
+            # previous group's PCIe transfer.  (Collectives are issued in the same order on
+            # every rank.)
+            groups = plan["rank_groups"]
+            npad = plan["npad"]
+            for a, b in groups:
+                if b - a > 1:
+                    ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, a | ((b - a) << 16))
+                else:
+                    ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, a)
+                plan["ev_ready"][a].record()
+            HW = plan["maps_dev"].shape[1]
+            host = plan["host"][slot].view(-1)
+            for i, (a, b) in enumerate(groups):
+                side = self._copy_stream if i & 1 else self._side_stream
+                with torch.cuda.stream(side):
+                    side.wait_event(plan["ev_ready"][a])
+                    g = plan["gathered_grp"][i]
+                    dist.all_gather_into_tensor(g[:-1], plan["depth"][a * npad:b * npad])
+                    ctx.stitch_rows(g, plan["stitch32_grp"][i], host[a * HW:b * HW])
+                    plan["ev_done"][a].record()
+                for k in range(a, b):
+                    plan["wait_ev"][k] = plan["ev_done"][a]
             return slot
         if dist is None and V >= 3 and self.options.depth_head:
             # one GPU: all images but the last decoded by ONE launch (no launch tails between

@@ -38,6 +38,9 @@ class PathOptions:
     plan_path: bool = True            # one C call per phase of a pass (rn_scene_run) when the pass qualifies
     depth_head: bool = True           # one GPU: all images but the last decoded by one launch
     direct_maps: bool = True          # no process group: the depth sweeps write pixel-order maps
+    rank_group: int = 2               # with a process group: images per depth launch + all-gather +
+    #                                   stitch of a rank (the last group takes the rest); 0: the
+    #                                   per-image exchange through index_select and a copy
     spin_wait: bool = False           # poll the maps' events instead of blocking on them
     # ---- memory ---------------------------------------------------------------------------
     resident_gb: float = 0.0          # HBM budget of the resident schedule; 0: 90 % of what is free
@@ -64,6 +67,7 @@ class PathOptions:
         "RAYNET_PLAN_PATH": ("plan_path", _flag),
         "RAYNET_DEPTH_HEAD": ("depth_head", _flag),
         "RAYNET_DIRECT_MAPS": ("direct_maps", _flag),
+        "RAYNET_RANK_GROUP": ("rank_group", int),
         "RAYNET_SPIN_WAIT": ("spin_wait", _flag),
         "RAYNET_RESIDENT_GB": ("resident_gb", float),
         "RAYNET_DETERMINISTIC": ("deterministic", _flag),
@@ -85,6 +89,7 @@ class PathOptions:
         assert self.exchange in ("allreduce", "reduce_scatter"), self.exchange
         assert self.scatter_mode in (-1, 0, 2) and self.box_level in (0, 1, 2)
         assert self.overlap in (0, 1, 2)
+        assert self.rank_group >= 0
 
     @classmethod
     def from_env(cls, environ=None, **overrides):
