@@ -713,8 +713,8 @@ __device__ __forceinline__ float map_planes_to_voxels(const Params &p,
 // Value arithmetic of the BP / depth kernels (never index-producing): hardware
 // reciprocal and log2 instead of the ~10-instruction IEEE division and ~15-instruction
 // logf sequences.  Each is within ~2 ulp; the messages' own fp32 conditioning
-// (eps * exp(|m|)) dominates that by far.  expf stays exact: its
-// error would be amplified by o/(1-o) next to the occupancy clamp.
+// (eps * exp(|m|)) dominates that by far.  The occupancy's exponential
+// is v_exp_f32 on the rounded product (below); -DRN_EXACT_OCC_EXP: the library sequence.
 #ifndef RN_EXACT_BP_MATH
 __device__ __forceinline__ float bp_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float bp_log(float x) {
@@ -729,11 +729,13 @@ __device__ __forceinline__ float occupancy_to_ray(float acc, float msg) {
     // t1 = exp(0 - max(0,mu)), t2 = exp(mu - max(0,mu)): one of the two is exp(0) = 1
     // exactly, the other exp(-|mu|) -- one exponential gives both, bit for bit
     const float mu = acc - msg;
-#ifdef RN_FAST_OCC_EXP
+#ifndef RN_EXACT_OCC_EXP
     // v_exp_f32 on -|mu| * log2(e): 2 instructions for the library's 11.  The product's
     // rounding makes exp(-|mu|) wrong by <= |mu| * 1.44 * 2^-24 relative: 8e-7 where the
-    // occupancy is not clamped anyway (|mu| <= 9.21), an order of magnitude below what the
-    // fp32 subtraction 1 - o already costs the transmittance next to the clamp (6e-8 / 1e-4)
+    // occupancy is not clamped anyway (|mu| <= 9.21; CUDA's own expf, what the reference runs,
+    // is specified to 2 ulp = 2.4e-7), an order of magnitude below what the fp32 subtraction
+    // 1 - o already costs the transmittance next to the clamp (6e-8 / 1e-4).  Full-size parity
+    // with the C oracle is unchanged by it; NaN and +-inf behave as expf.
     const float e = __builtin_amdgcn_exp2f(fabsf(mu) * -0x1.715476p+0f);
 #else
     const float e = exp_nonpos(0 - fabsf(mu));
