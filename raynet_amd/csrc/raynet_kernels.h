@@ -544,7 +544,15 @@ __device__ __forceinline__ void softmax_column(int D, int lane, float *Sl) {
     float sum = 0.0f;
     for (int k = lane; k < D; k += WAVE) {
         const float d = Sl[k] - mx;
+        // FAST (resident path, value-only): v_exp_f32 on the rounded product, as the occupancy's
+        // exponential: relative error <= |d| * 1.44 * 2^-24 on a term that
+        // is exp(d) of the column's sum -- below 1e-7 of it for any d
+#if !defined(RN_EXACT_OCC_EXP) && !defined(RN_EXACT_SOFTMAX_EXP)
+        const float v = FAST ? __builtin_amdgcn_exp2f(d * 0x1.715476p+0f)
+                             : (d <= 0.0f ? exp_nonpos(d) : expf(d));
+#else
         const float v = d <= 0.0f ? exp_nonpos(d) : expf(d);     // d > 0 only for NaN / inf input
+#endif
         Sl[k] = v;
         sum += v;
     }
