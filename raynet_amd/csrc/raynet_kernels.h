@@ -728,15 +728,28 @@ __device__ __forceinline__ float bp_div(float a, float b) { return a * __builtin
 __device__ __forceinline__ float bp_log(float x) {
     return __builtin_amdgcn_logf(x) * 0.6931471805599453f;    // v_log_f32 is log2
 }
+// log pos - log neg (the message, mrf_bp.cu:160-165): one multiplication by ln 2 for both
+__device__ __forceinline__ float bp_log_ratio(float pos, float neg) {
+    return (__builtin_amdgcn_logf(pos) - __builtin_amdgcn_logf(neg)) * 0.6931471805599453f;
+}
 #else
 __device__ __forceinline__ float bp_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float bp_log(float x) { return logf(x); }
+__device__ __forceinline__ float bp_log_ratio(float pos, float neg) { return logf(pos) - logf(neg); }
 #endif
 __device__ __forceinline__ float occupancy_to_ray(float acc, float msg) {
     // mrf_bp.cu:12-35
     // t1 = exp(0 - max(0,mu)), t2 = exp(mu - max(0,mu)): one of the two is exp(0) = 1
     // exactly, the other exp(-|mu|) -- one exponential gives both, bit for bit
     const float mu = acc - msg;
+#if !defined(RN_EXACT_OCC_EXP) && !defined(RN_OCC_TWO_TERMS)
+    // t2 / (t1 + t2) is 1 / (1 + exp(-mu)) on either side of 0; the reference forms it from
+    // exp(-|mu|) so that nothing overflows -- v_exp_f32 and v_rcp_f32 saturate instead (exp(-mu)
+    // = inf -> 0 -> the clamp's 1e-4, as the two-term form gives), NaN stays NaN.  Same error
+    // bound as below (the exponential's), three instructions fewer per voxel.
+    return clampf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mu * -0x1.715476p+0f)), 1e-4f,
+                  (float)(1 - 1e-4));
+#endif
 #ifndef RN_EXACT_OCC_EXP
     // v_exp_f32 on -|mu| * log2(e): 2 instructions for the library's 11.  The product's
     // rounding makes exp(-|mu|) wrong by <= |mu| * 1.44 * 2^-24 relative: 8e-7 where the

@@ -265,7 +265,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
                 // log pos - log neg: no normalisation, and no cancellation in 1 - p
                 const float pos = cex[ch] + tsv[ch];
                 const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
-                const float m = bp_log(pos) - bp_log(neg);
+                const float m = bp_log_ratio(pos, neg);
 #ifdef RN_EXP_BP_NOSTORE
                 if (m == 123.456f) row_store(mout_row, (unsigned)i, m);
 #else

@@ -393,7 +393,7 @@ __device__ __forceinline__ void first_sweep_messages(int count, int lane, float 
         const float cex = cex_row[i];
         const float pos = cex + ts_row[i];
         const float neg = cex + bp_div(col[i], 1.0f - o_const);
-        __builtin_nontemporal_store(bp_log(pos) - bp_log(neg), msg_row + i);    // (as k_bp's rows)
+        __builtin_nontemporal_store(bp_log_ratio(pos, neg), msg_row + i);    // (as k_bp's rows)
     }
 }
 
