@@ -71,6 +71,10 @@ __device__ __forceinline__ float gather_acc(const float *__restrict__ acc, int l
 #ifndef RN_BP_NT
 #define RN_BP_NT true
 #endif
+// bodies of up to this many chunks issue all their accumulator gathers back to back (bp_ray)
+#ifndef RN_GATHER_BATCH_MAX
+#define RN_GATHER_BATCH_MAX 6
+#endif
 template <int NCH>
 struct RayRows {
     float sv[NCH], mv[NCH];
@@ -103,10 +107,25 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
     const float *Srow = S + (size_t)r * p.M;
     const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
     const float *mrow = msgs ? msgs + (size_t)r * p.M : nullptr;
+    // the voxel words first, for all chunks: the accumulator gathers depend on them and on
+    // nothing else, and loads return in the order they were issued -- the columns and messages
+    // are still in flight while the gathers go out
+    constexpr bool VOX_FIRST = NCH <= RN_GATHER_BATCH_MAX;
+#pragma unroll
+    for (int ch = 0; ch < (VOX_FIRST ? NCH : 0); ch++) {
+        const int i = ch * WAVE + lane;
+        R.pk[ch] = 0;
+        // (a sweep over ONE constant accumulator value gathers nothing: no voxel row)
+        if (need_vox && ch * WAVE < count && i < count) {
+            if (PACKED) R.pk[ch] = row_load<NT>(vrow, (unsigned)i);
+            else R.pk[ch] = load_packed<PACKED>(vrow, i);
+        }
+    }
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         const int i = ch * WAVE + lane;
-        R.sv[ch] = 0.0f; R.mv[ch] = 0.0f; R.pk[ch] = 0;
+        R.sv[ch] = 0.0f; R.mv[ch] = 0.0f;
+        if (!VOX_FIRST) R.pk[ch] = 0;
         if (ch * WAVE < count && i < count) {
             // -DRN_EXP_NO_SR / -DRN_EXP_NO_MSG: timing experiments only (wrong results): how
             // much of the kernel's time is one 4-byte-per-voxel row read
@@ -115,8 +134,7 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
 #else
             R.sv[ch] = row_load<NT>(Srow, (unsigned)i);
 #endif
-            // (a sweep over ONE constant accumulator value gathers nothing: no voxel row)
-            if (need_vox) {
+            if (!VOX_FIRST && need_vox) {
                 if (PACKED) R.pk[ch] = row_load<NT>(vrow, (unsigned)i);
                 else R.pk[ch] = load_packed<PACKED>(vrow, i);
             }
@@ -172,20 +190,41 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
     float av[NB];
     const float a0 = uniform_acc ? (biased ? acc_bias : acc_in[0]) : 0.0f;
 #pragma unroll
-    for (int ch = 0; ch < NB; ch++) {
-        const int i = ch * WAVE + lane;
-        av[ch] = a0;
+    for (int ch = 0; ch < NB; ch++) av[ch] = a0;
 #ifndef RN_EXP_BP_NOGATHER      // timing experiments only (wrong results), as the ones below
-        if (!uniform_acc && ch * WAVE < count && i < count) {
-            av[ch] = gather_acc(acc_in, lin_of<PACKED>(p, cur.pk[ch]));
+    if (!uniform_acc) {
+        // All chunks' gathers are issued back to back and waited for ONCE: entries beyond the
+        // count hold voxel word 0 (load_rows) and gather accumulator entry 0 -- valid memory,
+        // the lanes are masked where the value would be used.  (Guarded per chunk, every
+        // gather sat in its own block with the addition that uses it and the wavefront paid
+        // NB dependent round trips in a row.)
+        // (Bodies of more than RN_GATHER_BATCH_MAX chunks -- config 4's M = 768 -- keep the
+        // guarded form: twelve gathers at once into a 67 MB accumulator were measured slower,
+        // k_bp 9.42 -> 9.80 ms per step there against 1.571 -> 1.515 at config 2.)
+        if (NB <= RN_GATHER_BATCH_MAX) {
+#pragma unroll
+            for (int ch = 0; ch < NB; ch++) av[ch] = gather_acc(acc_in, lin_of<PACKED>(p, cur.pk[ch]));
             // acc_in holds the messages' SUM only and the prior is added here (the same
             // `prior + sum` rn_acc_combine stores, without that kernel and its 3 G floats)
-            if (biased) av[ch] = acc_bias + av[ch];
+            if (biased) {
+#pragma unroll
+                for (int ch = 0; ch < NB; ch++) av[ch] = acc_bias + av[ch];
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < NB; ch++) {
+                const int i = ch * WAVE + lane;
+                if (ch * WAVE < count && i < count) {
+                    av[ch] = gather_acc(acc_in, lin_of<PACKED>(p, cur.pk[ch]));
+                    if (biased) av[ch] = acc_bias + av[ch];
+                }
+            }
         }
-#else
-        av[ch] = __builtin_bit_cast(float, cur.pk[ch]) * 1e-30f;
-#endif
     }
+#else
+#pragma unroll
+    for (int ch = 0; ch < NB; ch++) av[ch] = __builtin_bit_cast(float, cur.pk[ch]) * 1e-30f;
+#endif
 #ifdef RN_EXP_BP_NOCOMPUTE
     {
         float *mo = msgs_out + (size_t)r * p.M;
@@ -904,13 +943,23 @@ __device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int
     RayRows<NB> cur;
     load_rows<NB, PACKED>(p, cur, S, vox, msgs, r, count, lane);
     float av[NB];
+    if (NB <= RN_GATHER_BATCH_MAX) {
+        // (all gathers back to back, entries beyond the count gather entry 0: see bp_ray)
 #pragma unroll
-    for (int ch = 0; ch < NB; ch++) {
-        const int i = ch * WAVE + lane;
-        av[ch] = 0.0f;
-        if (ch * WAVE < count && i < count) {
-            av[ch] = gather_acc(acc, lin_of<PACKED>(p, cur.pk[ch]));
-            if (biased) av[ch] = acc_bias + av[ch];      // see bp_ray
+        for (int ch = 0; ch < NB; ch++) av[ch] = gather_acc(acc, lin_of<PACKED>(p, cur.pk[ch]));
+        if (biased) {
+#pragma unroll
+            for (int ch = 0; ch < NB; ch++) av[ch] = acc_bias + av[ch];
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < NB; ch++) {
+            const int i = ch * WAVE + lane;
+            av[ch] = 0.0f;
+            if (ch * WAVE < count && i < count) {
+                av[ch] = gather_acc(acc, lin_of<PACKED>(p, cur.pk[ch]));
+                if (biased) av[ch] = acc_bias + av[ch];      // see bp_ray
+            }
         }
     }
     clip_renorm_rows<NB, CLIP_IN>(cur.sv, count, lane);
