@@ -939,7 +939,7 @@ __device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int
                                           const int32_t *__restrict__ vox,
                                           const float *__restrict__ acc,
                                           const float *__restrict__ msgs, float *S_new, float &best,
-                                          int &best_i, float acc_bias, bool biased) {
+                                          int &best_i, int &best_pk, float acc_bias, bool biased) {
     RayRows<NB> cur;
     load_rows<NB, PACKED>(p, cur, S, vox, msgs, r, count, lane);
     float av[NB];
@@ -989,6 +989,7 @@ __device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int
             if (d > best) {   // ascending i per lane: keeps the first maximum
                 best = d;
                 best_i = i;
+                best_pk = cur.pk[ch];     // (its voxel word: no second trip to the list)
             }
         }
     }
@@ -1028,12 +1029,12 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const f
     }
     const int count = min(uniform(rvc[r]), p.M);
     float best = -INFINITY;
-    int best_i = 0;
+    int best_i = 0, best_pk = 0;
     if (count > 1) {
         const int nch = (count + WAVE - 1) / WAVE;
 #define RN_DE_BODY(NB) \
-    depth_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc, msgs, S_new, best, best_i, acc_bias, \
-                                   biased != 0)
+    depth_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc, msgs, S_new, best, best_i, best_pk, \
+                                   acc_bias, biased != 0)
         RN_DISPATCH_CHUNKS(NCH, nch, RN_DE_BODY);
 #undef RN_DE_BODY
     } else if (S_new) {
@@ -1046,15 +1047,28 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const f
     // all zeros and index 0 wins.  First maximum of the wave: the largest value (DPP
     // reduction), then the smallest index among the lanes that hold it -- two reductions on
     // the VALU instead of a six-step shuffle butterfly through LDS.
+    // The winning voxel's word is in the registers of the lane that holds the maximum: it is
+    // passed on from there instead of being read from the list again (one dependent round trip
+    // less at the end of every wavefront's life).
+    int won_pk = -1;
     {
         const float top = wave_max(best);
+        const int mine = best_i;
         best_i = wave_min_i(best == top ? best_i : 0x7fffffff);
+        const unsigned long long who = __ballot(best == top && mine == best_i);
+#ifndef RN_DEPTH_RELOAD_VOXEL
+        if (who) won_pk = __builtin_amdgcn_readlane(best_pk, (int)__builtin_ctzll(who));
+#endif
         if (best_i == 0x7fffffff) best_i = 0;       // (a NaN column: nobody equals the maximum)
     }
     if (lane == 0) {
         const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
         int x = 0, y = 0, z = 0;
-        if (count > 0) load_voxel<PACKED>(vrow, count > 1 ? best_i : 0, x, y, z);
+        if (count > 1 && won_pk >= 0) {
+            x = won_pk >> 20; y = (won_pk >> 10) & 1023; z = won_pk & 1023;
+        } else if (count > 0) {
+            load_voxel<PACKED>(vrow, count > 1 ? best_i : 0, x, y, z);
+        }
         const float pt[3] = {axes[x], axes[p.gx + y], axes[p.gx + p.gy + z]};
         float sum = 0.0f;
         for (int i = 0; i < 3; i++) {
