@@ -570,8 +570,9 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
 // voxels -- no assumption on the lists -- and a chunk whose box exceeds the LDS budget (rows
 // that are not patch-ordered) goes straight to the global atomics: always correct.
 // Tile shapes (rays x steps) and LDS capacity (voxels): 128 x 32 reads 128 B of every row per
-// round trip (whole cache lines) and is the default with 4096 voxels (32 KB, 5 workgroups per
-// CU); scenes whose bundles do not fit (fine grids, oblique views) first get 6144 voxels, then
+// round trip (whole cache lines) and is the default with 4096 voxels (32 KB + 720 B of tables and
+// 104 VGPRs: 4 workgroups per CU; 5 or 6 with smaller boxes were measured the same, DESIGN.md
+// section 5); scenes whose bundles do not fit (fine grids, oblique views) first get 6144 voxels, then
 // 256 x 16 tiles -- the kernel counts the chunks that overflowed and the launcher looks at
 // the previous launches' count (rn_ctx::box_*).
 __device__ __forceinline__ int wave_reduce_max(int x) { return lane63i(wave_scan_max(x)); }
