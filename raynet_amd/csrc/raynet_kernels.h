@@ -244,33 +244,77 @@ __device__ __forceinline__ int feature_offset(const Params &p, const float *__re
 // saturating v_cvt_i32_f32), a 24-bit multiply and a shift instead of two 32-bit multiplies,
 // and the two IEEE divisions only for the wavefronts in which some lane's quotient is too close
 // to a rounding boundary for round_quotient_fast (-DRN_IEEE_QUOTIENTS: always).
-template <int LOG2_VEC_BYTES>
-__device__ __forceinline__ int feature_offset_bytes(const Params &p,
-                                                    const float *__restrict__ Pv,
-                                                    const float point[3], float pad_shift) {
-    float x = 0.0f, y = 0.0f, n = 0.0f;
+// (in three pieces, so that a wavefront can project into ALL views first and decide once
+// whether any of them needs the IEEE quotients: sweep_coop)
+// 1: the matrix product and the quotients' fast form; `sure`: lanes whose x AND y quotients
+//    are certainly the IEEE division's (a lane mask)
+__device__ __forceinline__ void project_fast(const float *__restrict__ Pv, const float point[3],
+                                             float &x, float &y, float &n, float &rx, float &ry,
+                                             unsigned long long &sure) {
+    // The reference starts each sum at 0.0f (`x = 0; x += P0 * X; ...`).  0.0f + a is a for every
+    // a but -0 (and keeps NaN a NaN), so a sum started at its first product can differ from the
+    // literal one only in the sign of a zero result.  For the numerators that sign is lost:
+    // x = +-0 -> quotient +-0 (or NaN for n = 0 either way) -> rounds to +-0 -> + padding.  The
+    // DENOMINATOR keeps the literal form: the sign of n = 0 is the sign of an infinite quotient.
+    // (-DRN_PROJECTION_FROM_ZERO: all three literal.)
+#ifndef RN_PROJECTION_FROM_ZERO
+    x = Pv[0] * point[0]; y = Pv[4] * point[0]; n = 0.0f;
+    x += Pv[1] * point[1]; x += Pv[2] * point[2]; x += Pv[3] * 1;
+    y += Pv[5] * point[1]; y += Pv[6] * point[2]; y += Pv[7] * 1;
+    n += Pv[8] * point[0]; n += Pv[9] * point[1]; n += Pv[10] * point[2]; n += Pv[11] * 1;
+#else
+    x = 0.0f; y = 0.0f; n = 0.0f;
     x += Pv[0] * point[0]; x += Pv[1] * point[1]; x += Pv[2] * point[2]; x += Pv[3] * 1;
     y += Pv[4] * point[0]; y += Pv[5] * point[1]; y += Pv[6] * point[2]; y += Pv[7] * 1;
     n += Pv[8] * point[0]; n += Pv[9] * point[1]; n += Pv[10] * point[2]; n += Pv[11] * 1;
-#ifndef RN_IEEE_QUOTIENTS
+#endif
     const float rn = __builtin_amdgcn_rcpf(n);
     bool sure_x, sure_y;
-    float rx = round_quotient_fast(x, rn, sure_x), ry = round_quotient_fast(y, rn, sure_y);
-    if ((__builtin_amdgcn_ballot_w64(sure_x) & __builtin_amdgcn_ballot_w64(sure_y) &
-         __builtin_amdgcn_ballot_w64(reciprocal_is_normal(rn))) != __builtin_amdgcn_read_exec()) {         // ~4 % of the wavefronts per view at config 2
-        rx = round_half_away(x / n);
-        ry = round_half_away(y / n);
-    }
+    rx = round_quotient_fast(x, rn, sure_x);
+    ry = round_quotient_fast(y, rn, sure_y);
+    // (the class test straight into a lane mask: through ballot(bool) the compiler turns the
+    // v_cmp_class result into 0 / 1 and compares that again, two instructions per view)
+    unsigned long long normal_rcp;
+#ifndef RN_CLASS_VIA_BALLOT
+    asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(normal_rcp) : "v"(rn), "v"(0x108));
+#else
+    normal_rcp = __builtin_amdgcn_ballot_w64(reciprocal_is_normal(rn));
+#endif
+    sure = __builtin_amdgcn_ballot_w64(sure_x) & __builtin_amdgcn_ballot_w64(sure_y) & normal_rcp;
+}
+// 2: the reference's own quotients (feature_similarities.cu:31-36)
+__device__ __forceinline__ void project_ieee(float x, float y, float n, float &rx, float &ry) {
+    rx = round_half_away(x / n);
+    ry = round_half_away(y / n);
+}
+// 3: padding shift, clamp, the (0, 0) rule, byte offset of the vector in the view's map
+template <int LOG2_VEC_BYTES>
+__device__ __forceinline__ int project_offset(const Params &p, float rx, float ry, float pad_shift) {
     rx += pad_shift;
     ry += pad_shift;
-#else
-    const float rx = round_half_away(x / n) + pad_shift;
-    const float ry = round_half_away(y / n) + pad_shift;
-#endif
     const unsigned fx = (unsigned)(int)__builtin_amdgcn_fmed3f(rx, 0.0f, (float)p.W);
     const unsigned fy = (unsigned)(int)__builtin_amdgcn_fmed3f(ry, 0.0f, (float)p.H);
     const unsigned off = (__umul24(fy, (unsigned)p.Wf) + fx) << LOG2_VEC_BYTES;
     return min(fx, fy) == 0u ? 0 : (int)off;
+}
+template <int LOG2_VEC_BYTES>
+__device__ __forceinline__ int feature_offset_bytes(const Params &p,
+                                                    const float *__restrict__ Pv,
+                                                    const float point[3], float pad_shift) {
+    float x, y, n, rx, ry;
+#ifndef RN_IEEE_QUOTIENTS
+    unsigned long long sure;
+    project_fast(Pv, point, x, y, n, rx, ry, sure);
+    if (sure != __builtin_amdgcn_read_exec())         // ~4 % of the wavefronts per view at config 2
+        project_ieee(x, y, n, rx, ry);
+#else
+    x = 0.0f; y = 0.0f; n = 0.0f;
+    x += Pv[0] * point[0]; x += Pv[1] * point[1]; x += Pv[2] * point[2]; x += Pv[3] * 1;
+    y += Pv[4] * point[0]; y += Pv[5] * point[1]; y += Pv[6] * point[2]; y += Pv[7] * 1;
+    n += Pv[8] * point[0]; n += Pv[9] * point[1]; n += Pv[10] * point[2]; n += Pv[11] * 1;
+    project_ieee(x, y, n, rx, ry);
+#endif
+    return project_offset<LOG2_VEC_BYTES>(p, rx, ry, pad_shift);
 }
 
 __device__ __forceinline__ void plane_point(const float s[3], const float e[3], int k, int D,
@@ -475,16 +519,48 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             // requesting it one view ahead, staging the matrices in LDS -- the reloads' latency,
             // or the asm barriers between the views' projections, cost more than the spill code
             // (profiles/r03_exp_view_matrix_sgprs.txt).
+#if defined(RN_EXP_SWEEP_NOPROJ)      // timing experiment only (wrong results): no projection arithmetic
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+                offb[v] = (int)(((unsigned)(k * 977 + v * 131071 + lane * 8191) * 128u) & 0xffffffu);
+#elif !defined(RN_SWEEP_DECIDE_ONCE) || defined(RN_IEEE_QUOTIENTS)
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-#ifdef RN_EXP_SWEEP_NOPROJ      // timing experiment only (wrong results): no projection arithmetic
-                offb[v] = (int)(((unsigned)(k * 977 + v * 131071 + lane * 8191) * 128u) & 0xffffffu);
-#else
                 const float *Pv = P + 12 * v;
                 if (v >= RN_SWEEP_SGPR_VIEWS) asm volatile("" : "+s"(Pv));
                 offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, Pv, point, pad_shift);
-#endif
             }
+#else
+            // EXPERIMENT (-DRN_SWEEP_DECIDE_ONCE, measured slower: k_sweep_map 2.93 -> 3.00 ms):
+            // all views' fast projections first, ONE decision per chunk whether any view needs
+            // the IEEE quotients (18 % of the wavefronts at config 2, which then redo exactly
+            // the views that asked) instead of one branch per view
+            if (NV <= RN_SWEEP_UNROLL2_MAX_VIEWS) {
+                float px[NV], py[NV], pn[NV], rx[NV], ry[NV];
+                unsigned long long sure[NV], all = ~0ull;
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    project_fast(P + 12 * v, point, px[v], py[v], pn[v], rx[v], ry[v], sure[v]);
+                    all &= sure[v];
+                }
+                if (all != __builtin_amdgcn_read_exec()) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++)
+                        if (sure[v] != __builtin_amdgcn_read_exec())
+                            project_ieee(px[v], py[v], pn[v], rx[v], ry[v]);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+                    offb[v] = project_offset<LOG2_VEC_BYTES>(p, rx[v], ry[v], pad_shift);
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const float *Pv = P + 12 * v;
+                    if (v >= RN_SWEEP_SGPR_VIEWS) asm volatile("" : "+s"(Pv));
+                    offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, Pv, point, pad_shift);
+                }
+            }
+#endif
         }
         // View 0 is the reference image itself: every plane of the ray projects onto the
         // ray's own pixel there (up to the rounding of the projection, which is checked, not
