@@ -97,3 +97,37 @@ def test_hip_sweep_indices_follow_the_reference_projection(oracle_mod, case):
     fx, fy, clear = _expected_indices(pix, H, W)
     for form in (0, 1):
         assert np.array_equal(out[..., form][clear], (fy * Wf + fx)[clear]), (case, form)
+
+
+@pytest.mark.gpu
+def test_hip_sweep_indices_on_zero_sums_and_zero_denominators(oracle_mod):
+    """The cooperative sweep starts the projection's numerators at their first product instead of
+    `0.0f +` (raynet_kernels.h, project_fast): sums that come out as a zero of the other sign, zero
+    and negative-zero matrix entries, points with zero / negative-zero coordinates, and a
+    denominator that is exactly +0 or -0 (infinite or NaN quotients) must still give the
+    literal form's -- and the oracle's -- index, every sample."""
+    import torch
+    from raynet_amd.hip_implementations import get_context
+    H, W, D, V = 24, 32, 8, 5
+    rng = np.random.default_rng(17)
+    vals = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 3.0, -7.0, 1e-30, -1e-30], np.float32)
+    n = 4096
+    P = vals[rng.integers(0, 6, (n // 64, V, 12))].astype(np.float32)    # many exact cancellations
+    P[::3, :, 8:12] = vals[rng.integers(0, 2, (len(P[::3]), V, 4))]       # n = +-0 rows
+    P[1::5, :, 0:4] = vals[rng.integers(0, 2, (len(P[1::5]), V, 4))]      # x = +-0 rows
+    pts = vals[rng.integers(0, len(vals), (n, 3))].astype(np.float32)
+    ctxs = {}
+    bad = 0
+    for g in range(P.shape[0]):                  # one matrix set per 64 rays (a context per call is cheap)
+        start = pts[64 * g:64 * g + 64]
+        ctx = ctxs.setdefault(0, get_context(M=64, D=D, N=V, F=32, H=H, W=W, padding=PADDING,
+                                             bbox=(-1, -1, -1, 1, 1, 1), grid_shape=(4, 4, 4)))
+        out = torch.full((64, V, D, 2), -1, dtype=torch.int32, device="cuda")
+        ctx.selftest_feature_offsets(ctx.dev(P[g].reshape(-1)), ctx.dev(start), ctx.dev(start), out)
+        out = out.cpu().numpy().astype(np.int64)
+        o = oracle_mod.Oracle(M=8, D=D, N=V, F=4, H=H, W=W, padding=PADDING,
+                              bbox=[-1, -1, -1, 1, 1, 1], grid_shape=(2, 2, 2))
+        idx = o.feature_indices(P[g], start, start).astype(np.int64)
+        lin = idx[..., 1] * (W + PADDING + 1) + idx[..., 0]
+        bad += int((out[..., 0] != lin).sum() + (out[..., 1] != lin).sum())
+    assert bad == 0, bad
