@@ -510,9 +510,12 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             const int k = min(base + lane, p.D - 1);
             float point[3];
             plane_point(s, e, k, p.D, point);
-            // The 12 entries of a view's matrix are wave-uniform: scalar loads into SGPRs, all
-            // NV x 12 of them hoisted out of the chunk loop -- beyond 6 views more than there
-            // are: 125 SGPRs spilled at 9 views, ~300 v_writelane / v_readlane in the kernel.
+            // The 12 entries of a view's matrix are wave-uniform: scalar loads into SGPRs.  (While
+            // the class test below went through ballot(bool) the compiler hoisted all NV x 12 of
+            // them out of the chunk loop and at 9 views spilled 125 SGPRs, ~300 v_writelane /
+            // v_readlane in the kernel; with the test written as a lane mask it reloads the
+            // matrices per chunk and spills none -- 5.08 -> 4.11 G VALU instructions per launch
+            // at config 4.  What was tried against the spills before that:)
             // Every way of not spilling them was measured SLOWER at config 4 (17.0 -> 18.5 - 20.5
             // ms, with 11 % fewer VALU instructions): reloading a view's matrix where it is used
             // (the pointer made opaque by an empty asm; -DRN_SWEEP_SGPR_VIEWS=n: from view n on),
