@@ -99,7 +99,7 @@ __device__ __forceinline__ void row_store(T *row_uniform, unsigned i, T v) {
     else *(gT)((gb)row_uniform + i * (unsigned)sizeof(T)) = v;
 }
 // the first `count` entries of the ray's column, voxel list and (optionally) messages
-template <int NCH, bool PACKED, bool NT = false>
+template <int NCH, bool PACKED, bool NT = false, bool ALL_ROWS = false>
 __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
                                           const float *__restrict__ S,
                                           const int32_t *__restrict__ vox, const float *msgs, int r,
@@ -116,7 +116,7 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
         const int i = ch * WAVE + lane;
         R.pk[ch] = 0;
         // (a sweep over ONE constant accumulator value gathers nothing: no voxel row)
-        if (need_vox && ch * WAVE < count && i < count) {
+        if ((ALL_ROWS || need_vox) && ch * WAVE < count && i < count) {
             if (PACKED) R.pk[ch] = row_load<NT>(vrow, (unsigned)i);
             else R.pk[ch] = load_packed<PACKED>(vrow, i);
         }
@@ -134,12 +134,12 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
 #else
             R.sv[ch] = row_load<NT>(Srow, (unsigned)i);
 #endif
-            if (!VOX_FIRST && need_vox) {
+            if (!VOX_FIRST && (ALL_ROWS || need_vox)) {
                 if (PACKED) R.pk[ch] = row_load<NT>(vrow, (unsigned)i);
                 else R.pk[ch] = load_packed<PACKED>(vrow, i);
             }
 #ifndef RN_EXP_NO_MSG
-            if (mrow) R.mv[ch] = row_load<NT>(mrow, (unsigned)i);
+            if (ALL_ROWS || mrow) R.mv[ch] = row_load<NT>(mrow, (unsigned)i);
 #endif
         }
     }
@@ -175,15 +175,23 @@ __device__ __forceinline__ void clip_renorm_rows(float (&sv)[NCH], int count, in
     } while (0)
 
 // one BP sweep of one ray with NB >= ceil(count / 64) chunks (mrf_bp.cu:88-177)
-template <int NB, bool PACKED, bool CLIP_IN>
+// STEADY: an iteration after the first of the plan path -- messages exist, every voxel's
+// accumulator entry is gathered, the buffer holds sums and the prior is added at the gather.
+// Known at compile time, none of it is tested per chunk (as run-time flags each cost the load
+// section of a body two vector instructions and a branch per chunk and per row).
+template <int NB, bool PACKED, bool CLIP_IN, bool STEADY = false>
 __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int lane,
                                        const float *__restrict__ S,
                                        const int32_t *__restrict__ vox,
                                        const float *__restrict__ acc_in, const float *msgs_in,
                                        float *msgs_out, bool uniform_acc, float acc_bias,
                                        bool biased) {
+    if (STEADY) {
+        uniform_acc = false;
+        biased = true;
+    }
     RayRows<NB> cur;
-    load_rows<NB, PACKED, RN_BP_NT>(p, cur, S, vox, msgs_in, r, count, lane, !uniform_acc);
+    load_rows<NB, PACKED, RN_BP_NT, STEADY>(p, cur, S, vox, msgs_in, r, count, lane, !uniform_acc);
     // accumulator gather (depends on the voxel rows).  uniform_acc: every voxel holds
     // acc_in[0] (the first iteration starts from the prior everywhere) -- nothing to gather,
     // and with zero messages on top the occupancy is one constant for the whole sweep.
@@ -239,7 +247,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
     // const_o (iteration 0 of a pass: the prior everywhere, no messages yet): one occupancy
     // for the whole sweep.  Real (uniform) branches on it: as selects, every ray pays for the
     // constant's exponential AND every chunk for the per-voxel ones, whichever is used.
-    const bool const_o = uniform_acc && msgs_in == nullptr;
+    const bool const_o = !STEADY && uniform_acc && msgs_in == nullptr;
     float o_const = 0.0f;
     if (const_o) {
         asm volatile("" ::: "memory");      // (keeps the branch a branch)
@@ -315,7 +323,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
     }
 }
 
-template <int NCH, bool PACKED, bool CLIP_IN>
+template <int NCH, bool PACKED, bool CLIP_IN, bool STEADY = false>
 __global__ __launch_bounds__(RN_RAY_BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
                                               const int32_t *__restrict__ vox,
                                               const int32_t *__restrict__ rvc,
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_bp(Params p, int n, const floa
     if (count <= 1) return;   // mrf_np.py:300: such rays send nothing
     const int nch = (count + WAVE - 1) / WAVE;
 #define RN_BP_BODY(NB) \
-    bp_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc_in, msgs_in, msgs_out, uniform_acc != 0, \
+    bp_ray<NB, PACKED, CLIP_IN, STEADY>(p, r, count, lane, S, vox, acc_in, msgs_in, msgs_out, uniform_acc != 0, \
                                 acc_bias, biased != 0)
     RN_DISPATCH_CHUNKS(NCH, nch, RN_BP_BODY);
 #undef RN_BP_BODY
@@ -934,15 +942,20 @@ __global__ void k_acc_combine_fixed(unsigned long long *part, int64_t G, float p
 // Writes the distribution (if S_new) and/or the arg-max depth (if depth_map).
 // depth distribution of one ray with NB >= ceil(count / 64) chunks (mrf_bp.cu:37-86);
 // returns the lane's best (value, index) for the arg-max
-template <int NB, bool PACKED, bool CLIP_IN>
+// (STEADY: the plan path's depth sweep -- messages exist, sums + prior, no distribution written)
+template <int NB, bool PACKED, bool CLIP_IN, bool STEADY = false>
 __device__ __forceinline__ void depth_ray(const Params &p, int r, int count, int lane,
                                           const float *__restrict__ S,
                                           const int32_t *__restrict__ vox,
                                           const float *__restrict__ acc,
                                           const float *__restrict__ msgs, float *S_new, float &best,
                                           int &best_i, int &best_pk, float acc_bias, bool biased) {
+    if (STEADY) {
+        biased = true;
+        S_new = nullptr;
+    }
     RayRows<NB> cur;
-    load_rows<NB, PACKED>(p, cur, S, vox, msgs, r, count, lane);
+    load_rows<NB, PACKED, false, STEADY>(p, cur, S, vox, msgs, r, count, lane);
     float av[NB];
     if (NB <= RN_GATHER_BATCH_MAX) {
         // (all gathers back to back, entries beyond the count gather entry 0: see bp_ray)
@@ -1004,7 +1017,7 @@ struct DepthDest {
     int rows = 0;
     int64_t image_stride = 0;
 };
-template <int NCH, bool PACKED, bool CLIP_IN>
+template <int NCH, bool PACKED, bool CLIP_IN, bool STEADY = false>
 __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const float *S,
                                                  const int32_t *__restrict__ vox,
                                                  const int32_t *__restrict__ rvc,
@@ -1034,7 +1047,7 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const f
     if (count > 1) {
         const int nch = (count + WAVE - 1) / WAVE;
 #define RN_DE_BODY(NB) \
-    depth_ray<NB, PACKED, CLIP_IN>(p, r, count, lane, S, vox, acc, msgs, S_new, best, best_i, best_pk, \
+    depth_ray<NB, PACKED, CLIP_IN, STEADY>(p, r, count, lane, S, vox, acc, msgs, S_new, best, best_i, best_pk, \
                                    acc_bias, biased != 0)
         RN_DISPATCH_CHUNKS(NCH, nch, RN_DE_BODY);
 #undef RN_DE_BODY
