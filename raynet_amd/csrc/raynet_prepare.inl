@@ -338,6 +338,11 @@ __device__ unsigned long long g_phase[16];
 // stopped sweeping): 6 is best -- 2.80 ms against 2.91 at 7, 2.81 at 5, 2.84 at 4, 3.02 at 8.
 // The wide sweeps (two load rounds of 7+ views do not fit), the reference-layout variants
 // and the 4-view sweep (which would spill) are left alone
+// cache policy of the list's LDS-DMA loads: 2 = non-temporal (read once here; k_sweep_map 2.957 -> 2.904 ms
+// with it: the feature gathers keep the L2), 0 = default
+#ifndef RN_SWEEP_LIST_CPOL
+#define RN_SWEEP_LIST_CPOL 2
+#endif
 #ifndef RN_SWEEP_MIN_WAVES
 #define RN_SWEEP_MIN_WAVES 6
 #endif
@@ -486,7 +491,7 @@ void k_sweep_map(
             typedef __attribute__((address_space(3))) void *lptr;
             for (int c = 0; c < count; c += WAVE)
                 if (c + lane < p.M)
-                    __builtin_amdgcn_global_load_lds((gptr)(vrow + c + lane), (lptr)(vals + c), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr)(vrow + c + lane), (lptr)(vals + c), 4, 0, RN_SWEEP_LIST_CPOL);
             n_staged = (count + WAVE - 1) & ~(WAVE - 1);
         }
     }
