@@ -136,8 +136,17 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// utils.cu:1-3, min(max(x, a), b) with a < b: the median of the three, one v_med3_f32 -- which for
+// a NaN x returns min3 = a, what fmaxf(NaN, a) passes on (fminf / fmaxf each canonicalise their
+// argument first: three instructions; only a SIGNALLING NaN would differ, and every value the
+// path clamps is the result of an arithmetic instruction, which quiets it).  -DRN_CLAMP_MINMAX:
+// the literal form.
 __device__ __forceinline__ float clampf(float x, float a, float b) {
-    return fminf(fmaxf(x, a), b);   // utils.cu:1-3
+#ifndef RN_CLAMP_MINMAX
+    return __builtin_amdgcn_fmed3f(x, a, b);
+#else
+    return fminf(fmaxf(x, a), b);
+#endif
 }
 
 // ------------------------------------------------- exact arithmetic shortcuts

@@ -156,7 +156,8 @@ __device__ __forceinline__ void clip_renorm_rows(float (&sv)[NCH], int count, in
     for (int ch = 0; ch < NCH; ch++) {
         const int i = ch * WAVE + lane;
         float v = 0.0f;
-        if (i < count) v = clampf(sv[ch], (float)1e-5, (float)(1 - 1e-5));
+        // (the caller's raw column: the literal min / max, which also takes a signalling NaN to eps)
+        if (i < count) v = fminf(fmaxf(sv[ch], (float)1e-5), (float)(1 - 1e-5));
         sv[ch] = v;
         ssum += v;
     }

@@ -960,6 +960,14 @@ def test_mapping_shortcuts_are_exact(torch, D):
     planted = planted.view(np.float32)[:n // 2]
     t[:planted.size] = planted
     t[planted.size:planted.size + 8] = [0.0, 1e-4, 1.0, 1 - 1e-4, 2.0, -1.0, 9.9e-5, 0.99995]
+    # what the clamp (one v_med3_f32 for min(max(t, eps), 1 - eps)) does with values no ray
+    # produces: NaN of either sign and payload -> eps like fmaxf, infinities, zeros, denormals
+    special = np.array([np.nan, -np.nan, np.inf, -np.inf, -0.0, 0.0, 1e-45, -1e-45, 1e-39, 3e38,
+                        -3e38, 0.5], np.float32)
+    special[1] = np.uint32(0xffc00001).view(np.float32)
+    # (quiet NaNs only: every clamped value of the path is the result of an arithmetic
+    # instruction, which quiets a signalling NaN; v_med3_f32 would pass one on as 1 - eps)
+    t[-special.size:] = special
     out = torch.zeros((5, n), device="cuda")
     ctx.selftest_mapping(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(),
                          torch.from_numpy(t).cuda(), out)
@@ -983,6 +991,12 @@ def test_mapping_shortcuts_are_exact(torch, D):
     tc = np.clip(t, np.float32(1e-4), np.float32(1 - 1e-4))
     expect = (pos[None, 1:D] < tc[:4096, None]).sum(1)          # #{l >= 1 : pos[l] < t}
     assert np.array_equal(walk[:4096].astype(np.int64), expect)
+    with np.errstate(all="ignore"):
+        tcs = np.where(np.isnan(special), np.float32(1e-4),
+                       np.clip(special, np.float32(1e-4), np.float32(1 - 1e-4))).astype(np.float32)
+    expect = (pos[None, 1:D] < tcs[:, None]).sum(1)
+    assert np.array_equal(walk[-special.size:].astype(np.int64), expect), (walk[-special.size:], expect)
+    assert np.array_equal(table[-special.size:].astype(np.int64), expect)
 
 
 def test_rounded_quotient_shortcut(torch, oracle_mod):
