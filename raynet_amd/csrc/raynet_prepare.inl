@@ -361,6 +361,14 @@ __device__ __forceinline__ void first_sweep_messages(int count, int lane, float 
     // prior -- evaluated ONCE on the device (k_first_occupancy, the bits k_bp's own evaluation
     // gives) and handed in, instead of ~30 instructions per wavefront
     float carryT = 1.0f, carryC = 0.0f;
+#ifndef RN_FIRST_SWEEP_SCAN_PER_CHUNK
+    // The transmittance scan of a chunk multiplies the SAME constant 1 - o in every valid lane,
+    // and a lane's inclusive product depends on the lanes below it only: for every valid lane
+    // it is the scan of a full chunk, whichever chunk -- scanned once per wavefront, the very
+    // values (and the very carry, lane 63 of a full chunk) the per-chunk scans produce.
+    const float incl_full = wave_scan_mul(1.0f - o_const);
+    const float t_shift = wave_shift1(incl_full, 1.0f), t_carry = lane63(incl_full);
+#endif
     for (int base = 0; base < count; base += WAVE) {
         const int i = base + lane;
         const bool valid = i < count;
@@ -372,9 +380,14 @@ __device__ __forceinline__ void first_sweep_messages(int count, int lane, float 
             __builtin_nontemporal_store(sv, Sr_row + i);
         }
         const float o = valid ? o_const : 0.0f;
+#ifndef RN_FIRST_SWEEP_SCAN_PER_CHUNK
+        const float T = carryT * t_shift;
+        carryT = carryT * t_carry;
+#else
         const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
         const float T = carryT * wave_shift1(incl, 1.0f);
         carryT = carryT * lane63(incl);
+#endif
         const float ts = T * sv;
         const float w = valid ? o * ts : 0.0f;
         const float inclC = wave_scan_add(w);
