@@ -593,9 +593,10 @@ int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const 
     hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN, STEADY_>), dim3(ray_blocks_mrf(n)),          \
                        dim3(RN_RAY_BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, \
                        S_new, depth_map, rays_per_center, am.bias, am.biased ? 1 : 0, cc_stride, dest)
-    // (k_depth's STEADY form -- its flags known at compile time, as k_bp's -- was measured
-    // SLOWER, 0.746 -> 0.772 ms per step, where k_bp's gained 3 %: -DRN_DEPTH_STEADY builds it)
-#ifdef RN_DEPTH_STEADY
+    // (k_depth's STEADY form -- its flags known at compile time, as k_bp's: slower with plain
+    // row loads, 0.746 -> 0.772 ms per step, faster with the non-temporal ones, 0.717 -> 0.699;
+    // -DRN_DEPTH_NO_STEADY: the generic kernel)
+#ifndef RN_DEPTH_NO_STEADY
     const bool steady = PACKED && !CLIP_IN && msgs && !S_new && depth_map && am.biased;
 #else
     const bool steady = false;
