@@ -734,7 +734,11 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
 #else
             m[k] = msgs[(size_t)rr * p.M + ss];
 #endif
+#ifdef RN_EXP_NO_SCATTER_VOX      // timing experiment only (wrong results): no voxel-list stream
+            v[k] = 0;
+#else
             v[k] = load_packed<PACKED>(vox + (size_t)rr * p.M * (PACKED ? 1 : 3), ss);
+#endif
         }
     };
     auto process = [&](int s0, const float (&m)[BOX_NB], const int (&v)[BOX_NB], unsigned okmask) {
@@ -791,7 +795,12 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
 #pragma unroll
             for (int k = 0; k < BOX_NB; k++)
                 if (okmask >> k & 1) {
+#ifdef RN_EXP_NO_SCATTER_VOX
+                    const int x = lo0 + min(k & 3, d0 - 1), y = lo1 + min((tid >> 2) & 7, d1 - 1),
+                              z = lo2 + min(tid & 3, d2 - 1);
+#else
                     const int x = v[k] >> 20, y = (v[k] >> 10) & 1023, z = v[k] & 1023;
+#endif
 #ifdef RN_EXP_BOX_NOLDS         // timing experiment only (wrong results): no LDS atomics
                     asm volatile("" ::"v"(((x - lo0) * d1 + (y - lo1)) * d2 + (z - lo2)), "v"(m[k]));
 #else
