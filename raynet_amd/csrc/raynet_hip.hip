@@ -31,9 +31,12 @@ constexpr int NXCD = 8;
 // the box are long, border tiles are empty), so contiguous eighths leave some XCDs idle at the
 // end of a launch; what a kernel gains from locality decides its chunk
 // (profiles/r03_exp_xcd_chunk.txt): the plane sweep lives off neighbouring rays sharing feature
-// rows in L2 and wants its eighth, the scatter wants the balance.
+// rows in L2, the scatter wants the balance.  (The sweep had its eighth until its list loads
+// became non-temporal; re-measured after that, chunks of 256 - 1024 rays -- one to four 16 x 16
+// pixel tiles -- are 1.5 % faster at config 2 and 6.5 % at config 4, 64 rays are slower, 16384
+// much slower.)
 #ifndef RN_XCD_CHUNK_SWEEP
-#define RN_XCD_CHUNK_SWEEP 0
+#define RN_XCD_CHUNK_SWEEP 512
 #endif
 #ifndef RN_XCD_CHUNK_BP
 #define RN_XCD_CHUNK_BP 256
