@@ -9,7 +9,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libraynet_hip.so")
+# RAYNET_HIP_LIB: another BUILD of the same library (a variant from build(extra_flags=..., out=...));
+# its rn_version() says what it was built with
+LIB_PATH = os.environ.get("RAYNET_HIP_LIB") or os.path.join(CSRC, "libraynet_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "raynet_hip.h")
 
 HIPCC_FLAGS = [
@@ -28,20 +30,29 @@ class RaynetHipError(RuntimeError):
     pass
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).
+    extra_flags / out: a VARIANT build (A/B runs, the exact-arithmetic build of the tests) into
+    another path; the flags end up in rn_version() (RN_BUILD_EXTRA), so a variant can never
+    pass for the shipped library (tests/test_abi.py)."""
     srcs = [os.path.join(CSRC, "raynet_hip.hip"), os.path.join(CSRC, "raynet_kernels.h"),
             os.path.join(CSRC, "raynet_prepare.inl"), os.path.join(CSRC, "raynet_mrf.inl"),
             os.path.join(CSRC, "raynet_train.inl"), os.path.join(CSRC, "raynet_eval.inl"), HEADER]
-    if not force and os.path.exists(LIB_PATH) and \
-            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-        return LIB_PATH
+    extra = list(extra_flags) + os.environ.get("RAYNET_HIPCC_EXTRA", "").split()
+    target = out or LIB_PATH
+    if extra and out is None:
+        raise RaynetHipError("a variant build (%s) needs its own output path" % " ".join(extra))
+    if not force and os.path.exists(target) and \
+            all(os.path.getmtime(target) >= os.path.getmtime(s) for s in srcs):
+        return target
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [srcs[0], "-o", LIB_PATH]
+    cmd = [hipcc] + HIPCC_FLAGS + extra + [srcs[0], "-o", target]
+    if extra:
+        cmd.insert(1, '-DRN_BUILD_EXTRA="%s"' % " ".join(extra).replace('"', "'"))
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB_PATH
+    return target
 
 
 class Config(ctypes.Structure):

@@ -532,26 +532,6 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     // runs (on the context's second stream) while the second half's messages are computed.
     const size_t M = (size_t)ctx->p.M, VW = PACKED ? 1 : 3;
     const bool split = ctx->overlap == 1 || (ctx->overlap == 2 && level >= 1 && level < LAST);
-#ifdef RN_CHAIN_PIECES
-    // experiment (profiles/r03_exp_chain_pieces.txt): the rows in RN_CHAIN_PIECES pieces, each
-    // piece's scatter right behind its BP sweep, so that the scatter's reads of the messages
-    // (and of the voxel lists) find them in the L2 / Infinity Cache the sweep just filled
-    if (PACKED && !skip_bp && n >= 65536) {
-        const int piece = (n / RN_CHAIN_PIECES + 255) / 256 * 256;
-        bool first = true;
-        for (int r0 = 0; r0 < n; r0 += piece, first = false) {
-            const int m = min(piece, n - r0);
-            launch_bp_kernel<PACKED, CLIP_IN>(ctx, m, Sv + r0 * M, vox + r0 * M * VW, rvc + r0, acc_in,
-                                              msgs_in ? msgs_in + r0 * M : nullptr, msgs_out + r0 * M,
-                                              st, am, first);
-            RN_LAUNCH_CHECK(ctx);
-            launch_scatter_kernel<PACKED>(ctx, m, msgs_out + r0 * M, vox + r0 * M * VW, rvc + r0,
-                                          acc_out, st, level, fixed);
-            RN_LAUNCH_CHECK(ctx);
-        }
-        return RN_OK;
-    }
-#endif
     const int nA = split && PACKED && n >= 65536 && !skip_bp ? (n / 2 + 255) / 256 * 256 : n;
     if (!skip_bp) {     // (else: the plane sweep wrote the messages and cleared am.zero)
         launch_bp_kernel<PACKED, CLIP_IN>(ctx, nA, Sv, vox, rvc, acc_in, msgs_in, msgs_out, st, am, true);
@@ -633,7 +613,79 @@ int need_axes(rn_ctx *ctx) {
 
 extern "C" {
 
-const char *rn_version(void) { return "raynet_hip 0.1 (gfx950)"; }
+// The version string names every compile-time knob the library was built with (all of them
+// result-neutral A/B switches or the exact-arithmetic variants of DESIGN.md section 10a; the
+// timing-only ablations of earlier rounds live in tools/experiments/ as a patch, not here) and
+// whatever extra flags the build script passed (RN_BUILD_EXTRA): tests/test_abi.py holds the
+// shipped library to "knobs: none".
+#ifndef RN_BUILD_EXTRA
+#define RN_BUILD_EXTRA ""
+#endif
+const char *rn_version(void) {
+    static const char v[] = "raynet_hip 0.4 (gfx950) knobs:"
+#ifdef RN_EXACT_OCC_EXP
+        " RN_EXACT_OCC_EXP"
+#endif
+#ifdef RN_EXACT_SOFTMAX_EXP
+        " RN_EXACT_SOFTMAX_EXP"
+#endif
+#ifdef RN_EXACT_BP_MATH
+        " RN_EXACT_BP_MATH"
+#endif
+#ifdef RN_IEEE_QUOTIENTS
+        " RN_IEEE_QUOTIENTS"
+#endif
+#ifdef RN_MAP_WALK
+        " RN_MAP_WALK"
+#endif
+#ifdef RN_NO_FOLD_FIRST_SWEEP
+        " RN_NO_FOLD_FIRST_SWEEP"
+#endif
+#ifdef RN_OCC_TWO_TERMS
+        " RN_OCC_TWO_TERMS"
+#endif
+#ifdef RN_CLAMP_MINMAX
+        " RN_CLAMP_MINMAX"
+#endif
+#ifdef RN_PROJECTION_FROM_ZERO
+        " RN_PROJECTION_FROM_ZERO"
+#endif
+#ifdef RN_QUOTIENT_HALF_AWAY
+        " RN_QUOTIENT_HALF_AWAY"
+#endif
+#ifdef RN_PHASE_TIMERS
+        " RN_PHASE_TIMERS"
+#endif
+#ifdef RN_SCATTER_STATS
+        " RN_SCATTER_STATS"
+#endif
+#ifdef RN_BP_NO_STEADY
+        " RN_BP_NO_STEADY"
+#endif
+#ifdef RN_DEPTH_NO_STEADY
+        " RN_DEPTH_NO_STEADY"
+#endif
+#ifdef RN_OVERFLOW_BY_RESCAN
+        " RN_OVERFLOW_BY_RESCAN"
+#endif
+#ifdef RN_FIRST_SWEEP_SCAN_PER_CHUNK
+        " RN_FIRST_SWEEP_SCAN_PER_CHUNK"
+#endif
+#ifdef RN_HIDDEN_ARG_DIMS
+        " RN_HIDDEN_ARG_DIMS"
+#endif
+#ifdef RN_CLASS_VIA_BALLOT
+        " RN_CLASS_VIA_BALLOT"
+#endif
+#ifdef RN_DEPTH_RELOAD_VOXEL
+        " RN_DEPTH_RELOAD_VOXEL"
+#endif
+#ifdef RN_TRAV_SCALAR_FLUSH
+        " RN_TRAV_SCALAR_FLUSH"
+#endif
+        " | extra:" RN_BUILD_EXTRA;
+    return v;
+}
 
 const char *rn_last_error(const rn_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 

@@ -56,12 +56,8 @@ __device__ __forceinline__ int dpp_i(int old, int src) {
 // instructions per step for mul / max and for the two row_bcast steps of add (materialise
 // the identity, v_mov_dpp, op).  `s_nop 1`
 // covers the VALU-write -> DPP-read hazard, which the assembler does not insert inside asm.
-#ifdef RN_EXP_NO_DPP_NOPS     // timing experiment only (WRONG results: the hazard is real)
-#define RN_SCAN_STEP(OP, X, CTRL) asm(OP " %0, %0, %0 " CTRL : "+v"(X))
-#else
 #define RN_SCAN_STEP(OP, X, CTRL) \
     asm("s_nop 1\n\t" OP " %0, %0, %0 " CTRL : "+v"(X))
-#endif
 #define RN_WAVE_SCAN(OP, X)                                             \
     RN_SCAN_STEP(OP, X, "row_shr:1 row_mask:0xf bank_mask:0xf");        \
     RN_SCAN_STEP(OP, X, "row_shr:2 row_mask:0xf bank_mask:0xf");        \
@@ -405,14 +401,7 @@ __device__ __forceinline__ float sweep_round(const float *const (&vbase)[NV], co
         }
         // byte offset from a uniform GLOBAL base: loads with a 32-bit register offset
         // (global_load ... s[base]), no 64-bit address arithmetic per lane
-        // -DRN_EXP_SWEEP_WINDOW=<mask>: timing experiment only (wrong results) -- every gather
-        // falls into a window of <mask>+1 bytes of its map: what the sweep costs when its
-        // feature vectors come from L1 (16 KB window) / from L2 (2 MB window)
-#ifdef RN_EXP_SWEEP_WINDOW
-        const unsigned ob = (((unsigned)__shfl(offb[v], src)) & (unsigned)(RN_EXP_SWEEP_WINDOW) & ~127u) + part_bytes;
-#else
         const unsigned ob = (unsigned)__shfl(offb[v], src) + part_bytes;
-#endif
         typedef const __attribute__((address_space(1))) char *gptr;
         typedef const __attribute__((address_space(1))) float4v *gptr4;
 #pragma unroll
@@ -531,48 +520,12 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             // requesting it one view ahead, staging the matrices in LDS -- the reloads' latency,
             // or the asm barriers between the views' projections, cost more than the spill code
             // (profiles/r03_exp_view_matrix_sgprs.txt).
-#if defined(RN_EXP_SWEEP_NOPROJ)      // timing experiment only (wrong results): no projection arithmetic
-#pragma unroll
-            for (int v = 0; v < NV; v++)
-                offb[v] = (int)(((unsigned)(k * 977 + v * 131071 + lane * 8191) * 128u) & 0xffffffu);
-#elif !defined(RN_SWEEP_DECIDE_ONCE) || defined(RN_IEEE_QUOTIENTS)
 #pragma unroll
             for (int v = 0; v < NV; v++) {
                 const float *Pv = P + 12 * v;
                 if (v >= RN_SWEEP_SGPR_VIEWS) asm volatile("" : "+s"(Pv));
                 offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, Pv, point, pad_shift);
             }
-#else
-            // EXPERIMENT (-DRN_SWEEP_DECIDE_ONCE, measured slower: k_sweep_map 2.93 -> 3.00 ms):
-            // all views' fast projections first, ONE decision per chunk whether any view needs
-            // the IEEE quotients (18 % of the wavefronts at config 2, which then redo exactly
-            // the views that asked) instead of one branch per view
-            if (NV <= RN_SWEEP_UNROLL2_MAX_VIEWS) {
-                float px[NV], py[NV], pn[NV], rx[NV], ry[NV];
-                unsigned long long sure[NV], all = ~0ull;
-#pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    project_fast(P + 12 * v, point, px[v], py[v], pn[v], rx[v], ry[v], sure[v]);
-                    all &= sure[v];
-                }
-                if (all != __builtin_amdgcn_read_exec()) {
-#pragma unroll
-                    for (int v = 0; v < NV; v++)
-                        if (sure[v] != __builtin_amdgcn_read_exec())
-                            project_ieee(px[v], py[v], pn[v], rx[v], ry[v]);
-                }
-#pragma unroll
-                for (int v = 0; v < NV; v++)
-                    offb[v] = project_offset<LOG2_VEC_BYTES>(p, rx[v], ry[v], pad_shift);
-            } else {
-#pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    const float *Pv = P + 12 * v;
-                    if (v >= RN_SWEEP_SGPR_VIEWS) asm volatile("" : "+s"(Pv));
-                    offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, Pv, point, pad_shift);
-                }
-            }
-#endif
         }
         // View 0 is the reference image itself: every plane of the ray projects onto the
         // ray's own pixel there (up to the rounding of the projection, which is checked, not

@@ -130,20 +130,12 @@ __device__ __forceinline__ void load_rows(const Params &p, RayRows<NCH> &R,
         R.sv[ch] = 0.0f; R.mv[ch] = 0.0f;
         if (!VOX_FIRST) R.pk[ch] = 0;
         if (ch * WAVE < count && i < count) {
-            // -DRN_EXP_NO_SR / -DRN_EXP_NO_MSG: timing experiments only (wrong results): how
-            // much of the kernel's time is one 4-byte-per-voxel row read
-#ifdef RN_EXP_NO_SR
-            R.sv[ch] = 1.0f / count;
-#else
             R.sv[ch] = row_load<NT>(Srow, (unsigned)i);
-#endif
             if (!VOX_FIRST && (ALL_ROWS || need_vox)) {
                 if (PACKED) R.pk[ch] = row_load<NT>(vrow, (unsigned)i);
                 else R.pk[ch] = load_packed<PACKED>(vrow, i);
             }
-#ifndef RN_EXP_NO_MSG
             if (ALL_ROWS || mrow) R.mv[ch] = row_load<NT>(mrow, (unsigned)i);
-#endif
         }
     }
 }
@@ -203,7 +195,6 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
     const float a0 = uniform_acc ? (biased ? acc_bias : acc_in[0]) : 0.0f;
 #pragma unroll
     for (int ch = 0; ch < NB; ch++) av[ch] = a0;
-#ifndef RN_EXP_BP_NOGATHER      // timing experiments only (wrong results), as the ones below
     if (!uniform_acc) {
         // All chunks' gathers are issued back to back and waited for ONCE: entries beyond the
         // count hold voxel word 0 (load_rows) and gather accumulator entry 0 -- valid memory,
@@ -233,21 +224,6 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
             }
         }
     }
-#else
-#pragma unroll
-    for (int ch = 0; ch < NB; ch++) av[ch] = __builtin_bit_cast(float, cur.pk[ch]) * 1e-30f;
-#endif
-#ifdef RN_EXP_BP_NOCOMPUTE
-    {
-        float *mo = msgs_out + (size_t)r * p.M;
-#pragma unroll
-        for (int ch = 0; ch < NB; ch++) {
-            const int i = ch * WAVE + lane;
-            if (ch * WAVE < count && i < count) row_store(mo, (unsigned)i, cur.sv[ch] + cur.mv[ch] + av[ch]);
-        }
-        return;
-    }
-#endif
     // const_o (iteration 0 of a pass: the prior everywhere, no messages yet): one occupancy
     // for the whole sweep.  Real (uniform) branches on it: as selects, every ray pays for the
     // constant's exponential AND every chunk for the per-voxel ones, whichever is used.
@@ -317,11 +293,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
                 const float pos = cex[ch] + tsv[ch];
                 const float neg = cex[ch] + bp_div(suf[ch], 1.0f - ov[ch]);
                 const float m = bp_log_ratio(pos, neg);
-#ifdef RN_EXP_BP_NOSTORE
-                if (m == 123.456f) row_store(mout_row, (unsigned)i, m);
-#else
                 row_store<RN_BP_NT>(mout_row, (unsigned)i, m);
-#endif
             }
         }
     }
@@ -553,13 +525,9 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
                 }
 #endif
                 if (emit) {
-#ifdef RN_SCATTER_NOATOMIC       // timing experiment only: everything but the atomic
-                    asm volatile("" ::"v"(lin), "v"(val));
-#else
                     if (tail)
                         __hip_atomic_fetch_add(acc_out + lin, val, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
-#endif
                     cursor++;
                     if (cursor < nvalid) vcur = tile_v[lane * SLAB_PAD + cursor];
                 }
@@ -705,11 +673,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
         for (int i = tid; i < V; i += BLOCK) {
             const typename Sum::box_t bv = box[i];
             box[i] = 0;                 // the box is all zero again when the next chunk starts
-#ifdef RN_EXP_BOX_NOFLUSH       // timing experiment only (wrong results): no global atomics
-            asm volatile("" ::"v"(bv));
-#else
             Sum::flush(acc_out, lin_xyz<PACKED>(p, lo0 + i0, lo1 + i1, lo2 + i2), bv);
-#endif
             i2 += sz;
             if (i2 >= d2) { i2 -= d2; i1++; }
             i1 += sy;
@@ -729,16 +693,8 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             okmask |= (unsigned)ok << k;
             // rows of padding / short rays are read at the tile's first row: valid memory
             const int rr = ok ? r0 + j0 + k * STRIDE : r0, ss = ok ? st : 0;
-#ifdef RN_EXP_NO_SCATTER_MSG      // timing experiment only (wrong results)
-            m[k] = 1.0f;
-#else
             m[k] = msgs[(size_t)rr * p.M + ss];
-#endif
-#ifdef RN_EXP_NO_SCATTER_VOX      // timing experiment only (wrong results): no voxel-list stream
-            v[k] = 0;
-#else
             v[k] = load_packed<PACKED>(vox + (size_t)rr * p.M * (PACKED ? 1 : 3), ss);
-#endif
         }
     };
     auto process = [&](int s0, const float (&m)[BOX_NB], const int (&v)[BOX_NB], unsigned okmask) {
@@ -795,19 +751,10 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
 #pragma unroll
             for (int k = 0; k < BOX_NB; k++)
                 if (okmask >> k & 1) {
-#ifdef RN_EXP_NO_SCATTER_VOX
-                    const int x = lo0 + min(k & 3, d0 - 1), y = lo1 + min((tid >> 2) & 7, d1 - 1),
-                              z = lo2 + min(tid & 3, d2 - 1);
-#else
                     const int x = v[k] >> 20, y = (v[k] >> 10) & 1023, z = v[k] & 1023;
-#endif
-#ifdef RN_EXP_BOX_NOLDS         // timing experiment only (wrong results): no LDS atomics
-                    asm volatile("" ::"v"(((x - lo0) * d1 + (y - lo1)) * d2 + (z - lo2)), "v"(m[k]));
-#else
                     __hip_atomic_fetch_add(box + box_index(x - lo0, y - lo1, z - lo2, d1, d2),
                                            Sum::from_msg(m[k]), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
                 }
             __syncthreads();
             flush_box(lo0, lo1, lo2, d0, d1, d2);

@@ -130,7 +130,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
     int cx = cur[0], cy = cur[1], cz = cur[2];
     float tx = tm[0], ty = tm[1], tz = tm[2];
     int count = 0;           // voxels emitted so far by this ray
-#if !defined(RN_TRAV_BRANCHES) && !defined(RN_TRAV_COORDS)
     // The walk on the PACKED voxel word: a step adds +-1 to one 10-bit field (a field that
     // leaves [0, g) may borrow from / carry into its neighbour -- the ray is switched off in
     // that very step and the word never emitted), the end test is one comparison of words,
@@ -144,9 +143,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
     const int ux = step[0] * (1 << 20), uy = step[1] * (1 << 10), uz = step[2];
     int room_x = step[0] > 0 ? g[0] - 1 - cx : cx, room_y = step[1] > 0 ? g[1] - 1 - cy : cy,
         room_z = step[2] > 0 ? g[2] - 1 - cz : cz;
-#endif
     // `active` = this ray still has a voxel (cx,cy,cz) to emit at index `count`
-#if !defined(RN_TRAV_BRANCHES) && !defined(RN_TRAV_COORDS)
     // one step of an active ray: emit, then advance (ray_tracing.pyx:166-197).  Everything is
     // computed unconditionally and the ray switched off at the end -- a ray that has just
     // emitted its last voxel moves once more into a word nobody reads.  `count >= M` is the
@@ -173,10 +170,8 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
     // the grid): voxels emitted = moves made = what the three counters have lost
     const int room_sum0 = room_x + room_y + room_z;
     const bool whole_tiles = p.M % TRAV_TILE == 0;
-#endif
     for (int base = 0; base < p.M; base += TRAV_TILE) {
         if (__ballot(active) == 0) break;
-#if !defined(RN_TRAV_BRANCHES) && !defined(RN_TRAV_COORDS)
         if (whole_tiles) {
 #pragma unroll
             for (int k = 0; k < TRAV_TILE; k++) { RN_DDA_STEP(k) }
@@ -184,58 +179,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
             for (int k = 0; k < TRAV_TILE && base + k < p.M; k++) { RN_DDA_STEP(k) }
         }
         count = room_sum0 - (room_x + room_y + room_z);
-#else
-        for (int k = 0; k < TRAV_TILE && base + k < p.M; k++) {
-            if (active) {
-                if (vox) tile[lane * (TRAV_TILE + 1) + k] = pack_voxel(cx, cy, cz);
-                count++;
-                // advance (ray_tracing.pyx:166-197)
-                if ((cx == last[0] && cy == last[1] && cz == last[2]) || count >= p.M) {
-                    active = false;
-#ifndef RN_TRAV_BRANCHES
-                } else {
-                    // the same choice and the same additions as the branches below
-                    // (-DRN_TRAV_BRANCHES), as selects: the axes that do not move add 0 to their
-                    // index and +0.0f to their t (exact).  Four divergent branches per step cost
-                    // the wavefront all four bodies: 0.43 -> 0.35 ms per scene
-                    const bool a = tx < ty, b = tx < tz, c = ty < tz;
-                    const bool mx = a & b, my = !a & c, mz = !(mx | my);
-                    cx += mx ? step[0] : 0;
-                    cy += my ? step[1] : 0;
-                    cz += mz ? step[2] : 0;
-                    tx += mx ? td[0] : 0.0f;
-                    ty += my ? td[1] : 0.0f;
-                    tz += mz ? td[2] : 0.0f;
-                    if ((unsigned)cx >= (unsigned)g[0] || (unsigned)cy >= (unsigned)g[1] ||
-                        (unsigned)cz >= (unsigned)g[2])
-                        active = false;
-                }
-#else
-                } else if (tx < ty) {
-                    if (tx < tz) {
-                        cx += step[0];
-                        if (cx < 0 || cx >= g[0]) active = false;
-                        tx += td[0];
-                    } else {
-                        cz += step[2];
-                        if (cz < 0 || cz >= g[2]) active = false;
-                        tz += td[2];
-                    }
-                } else {
-                    if (ty < tz) {
-                        cy += step[1];
-                        if (cy < 0 || cy >= g[1]) active = false;
-                        ty += td[1];
-                    } else {
-                        cz += step[2];
-                        if (cz < 0 || cz >= g[2]) active = false;
-                        tz += td[2];
-                    }
-                }
-#endif
-            }
-        }
-#endif
         if (!vox) continue;          // count-only launch (rn_scene_count_voxels): nothing to flush
         wave_sync();
         // Bounding box of the voxels these 64 rays emitted in this slab of steps, for the
@@ -522,9 +465,6 @@ void k_sweep_map(
     }
     wave_sync();
     RN_PHASE_MARK(3);                      // softmax
-#ifdef RN_EXP_SWEEP_NOMAP       // timing experiment only (wrong results): no planes -> voxels
-    if (RESIDENT) return;
-#endif
 
     if (MAPMODE == 0) {
         for (int k = lane; k < p.D; k += WAVE) S_planes[(size_t)r * p.D + k] = Sl[k];

@@ -25,7 +25,21 @@ def test_library_builds_and_exports_header_symbols():
         assert hasattr(lib, n), "missing export %s" % n
     assert sorted(_lib.SIGNATURES) == names     # the ctypes table covers the whole header
     _lib.load()
-    assert lib.rn_version
+    # the shipped library is the DEFAULT build: no exact-arithmetic / statistics / A-B knob and no
+    # extra compiler flag went into it (rn_version() names every one that did)
+    lib.rn_version.restype = ctypes.c_char_p
+    version = lib.rn_version().decode()
+    assert version.startswith("raynet_hip") and version.endswith("knobs: | extra:"), version
+
+
+def test_no_timing_only_branches_in_the_product_sources():
+    """The ablation switches of earlier rounds (results wrong on purpose) live in
+    tools/experiments/ as a patch; the translation unit that ships has none."""
+    csrc = os.path.join(REPO, "raynet_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".inl")):
+            src = open(os.path.join(csrc, f)).read()
+            assert "RN_EXP" not in src and "wrong results" not in src.lower(), f
 
 
 def test_no_device_is_an_error_not_a_fallback():
