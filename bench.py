@@ -247,6 +247,10 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx = fp._ctx
+    # N > 1: every exchange of the breakdown steps (the all-reduce per BP iteration, the depth
+    # rows' way to their owners) is bracketed by a pair of events on its stream (fp.trace)
+    if world > 1:
+        fp.trace = []
     # Per-kernel breakdown: untimed steps with every launch bracketed by an event pair.  The
     # timed region then brackets the launches of the dominant family only (--events all: every
     # launch, as the breakdown steps do): an event pair costs the stream a few microseconds,
@@ -258,6 +262,23 @@ def main():
         step()
     fence()
     launches_all = ctx.prof_end()
+    exchange_ms = {}
+    if fp.trace is not None:
+        open_ev = {}
+        for name, begin, ev in fp.trace:
+            if begin:
+                open_ev[name] = ev
+            else:
+                exchange_ms[name] = exchange_ms.get(name, 0.0) + open_ev.pop(name).elapsed_time(ev)
+        exchange_ms = {k: v / breakdown_steps for k, v in exchange_ms.items()}
+        fp.trace = None
+    # the step is recorded into ONE HIP graph once the scatter's adaptive tile shape has settled
+    # (a dozen scatter launches after the plan was built): the remaining untimed passes until
+    # then -- the same number on every rank, the criterion counts launches
+    extra_warmup = 0
+    while fp.options.capture and not fp.captured and extra_warmup < 8:
+        step()
+        extra_warmup += 1
     # Which family dominates: by its SHARE of the timeline, not by the sum of its launches'
     # durations -- with the second stream on (config 4: the scatter of one half of the rows next
     # to k_bp of the other) concurrent launches would each be charged the whole overlap.  An
@@ -280,10 +301,35 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     launches = ctx.prof_end()
+    ranks_report = None
     if world > 1:
+        # what every rank saw: its own wall time for the K steps, its kernel families' sums and
+        # its exchanges (breakdown steps, eager), its share of the rays and of the voxel visits
+        mine = dict(ms_per_step=elapsed / args.steps * 1e3,
+                    exchange_ms_per_step=exchange_ms.get("exchange", 0.0),
+                    gather_ms_per_step=exchange_ms.get("gather", 0.0),
+                    kernel_ms_per_step=sum(ms for _, _, ms in launches_all) / breakdown_steps,
+                    rows=int(sum(len(fp.ray_index[r]) for r in fp.ray_index)))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        keys = ("ms_per_step", "exchange_ms_per_step", "gather_ms_per_step", "kernel_ms_per_step")
+        ranks_report = {k: [round(g[k], 4) for g in gathered] for k in keys}
+        ranks_report["rows"] = [g["rows"] for g in gathered]
+        ranks_report["ms_per_step_min_max"] = [round(min(ranks_report["ms_per_step"]), 4),
+                                               round(max(ranks_report["ms_per_step"]), 4)]
+        if fp.shard_balance is not None:
+            bal = np.array(fp.shard_balance, dtype=np.float64).sum(0)
+            ranks_report["voxel_share_over_mean"] = np.round(bal / bal.mean(), 4).tolist()
+        ranks_report["what"] = (
+            "per rank, in rank order.  ms_per_step: the rank's own clock over the timed steps (the "
+            "line's ms_per_step is the maximum).  exchange / gather: event-bracketed collectives of "
+            "the untimed breakdown steps, eager schedule -- all-reduce of the partial accumulators "
+            "(3 per step) / the depth rows' way to the maps' owners; a rank that arrives early "
+            "waits inside them, so they hold the imbalance too.  kernel: sum of the rank's "
+            "launches.  rows, voxel_share_over_mean: the shard.")
 
     rays_per_step = V * H * W
     value = rays_per_step * args.steps / elapsed
@@ -503,6 +549,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": kernels,
+            "ranks": ranks_report,
+            "step_capture": {"captured": bool(fp.captured), "extra_warmup_steps": extra_warmup},
             "kernel_events": {"breakdown_steps_untimed": breakdown_steps,
                               "timed_region": "all launches" if only is None else
                               "launches of %s only" % dominant},

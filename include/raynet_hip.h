@@ -244,6 +244,13 @@ int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int3
  * many of them did not fit the LDS box. */
 int rn_scatter_state(const rn_ctx *ctx, int32_t *level, uint32_t *chunks, uint32_t *overflowed);
 
+/* 1 once the scatter no longer copies its overflow counters out (a dozen launches after
+ * rn_create / rn_scatter_reset / rn_set_options): from then on no launch of the resident path
+ * touches the host and the tile shape stays as it is -- the precondition for recording a step's
+ * launches into a HIP graph (the reference has no counterpart: PyCUDA launches one kernel at a
+ * time from the interpreter, cuda_implementations/raynet_fp.py:303-326). */
+int rn_scatter_settled(const rn_ctx *ctx);
+
 /* Voxel counts only (the traversal of rn_scene_prepare_all without its lists): rvc
  * [n_images][n] i32, row g*n + i = number of voxels ray ray_idxs[i] crosses in reference image
  * g (<= M).  The multi-GPU driver balances its ray shards by these counts (the cost of the BP

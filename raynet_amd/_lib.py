@@ -127,6 +127,7 @@ SIGNATURES = {
     "rn_scene_bind_slab_boxes": [_P, _P, _L, _P],
     "rn_scatter_state": [_P, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_uint32),
                          ctypes.POINTER(ctypes.c_uint32)],
+    "rn_scatter_settled": [_P],
     "rn_acc_size": [_P],
     "rn_acc_to_grid": [_P, _P, _P, _P],
     "rn_stitch_rows": [_P, _L, _P, _P, _P, _P],

@@ -250,6 +250,8 @@ struct rn_ctx {
     unsigned *box_stats, *box_stats_host;
     unsigned box_seen[2], box_obs[2];
     int box_probe;
+    bool box_probe_used;  // some scatter has run since the context was created
+    bool box_rebase;      // after a reset: the next counters that arrive are a baseline, not an observation
     // occupancy_to_ray(prior, 0) as the device evaluates it, for the prior it was last asked for
     float first_prior, first_occ;
     bool have_first_occ;
@@ -514,7 +516,13 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
     int level = ctx->scatter_mode == 0 ? LAST : (ctx->scatter_mode == 2 || patch_rows) ? 0 : LAST;
     if (level == 0) {
         const unsigned c0 = ctx->box_stats_host[0], c1 = ctx->box_stats_host[1];
-        if (c0 != ctx->box_seen[0]) {          // counters of more launches have arrived
+        if (c0 != ctx->box_seen[0] && ctx->box_rebase) {
+            // the counters are cumulative and were last looked at before the reset: what has
+            // arrived mixes launches of the previous scene / tile shape in -- a baseline only
+            ctx->box_seen[0] = c0;
+            ctx->box_seen[1] = c1;
+            ctx->box_rebase = false;
+        } else if (c0 != ctx->box_seen[0]) {   // counters of more launches have arrived
             ctx->box_obs[0] = c0 - ctx->box_seen[0];
             ctx->box_obs[1] = c1 - ctx->box_seen[1];
             ctx->box_seen[0] = c0;
@@ -555,10 +563,12 @@ int launch_bp(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const int
         launch_scatter_kernel<PACKED>(ctx, n, msgs_out, vox, rvc, acc_out, st, level, fixed);
         RN_LAUNCH_CHECK(ctx);
     }
-    if (level < LAST && ctx->box_probe > 0) {
+    ctx->box_probe_used = true;
+    if (ctx->box_probe > 0) {
         ctx->box_probe--;
-        (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
-                             hipMemcpyDeviceToHost, st);
+        if (level < LAST)
+            (void)hipMemcpyAsync(ctx->box_stats_host, ctx->box_stats, 2 * sizeof(unsigned),
+                                 hipMemcpyDeviceToHost, st);
     }
     RN_LAUNCH_CHECK(ctx);
     return RN_OK;
@@ -792,6 +802,7 @@ int rn_set_options(rn_ctx *ctx, const rn_options *opt) {
     ctx->generic_sweep = opt->generic_sweep != 0;
     ctx->box_obs[0] = ctx->box_obs[1] = 0;
     ctx->box_probe = BOX_PROBE_LAUNCHES;
+    ctx->box_rebase = ctx->box_probe_used;
     return RN_OK;
 }
 
@@ -1038,7 +1049,15 @@ int rn_scatter_reset(rn_ctx *ctx) {
     ctx->box_level = ctx->box_level0;
     ctx->box_obs[0] = ctx->box_obs[1] = 0;
     ctx->box_probe = BOX_PROBE_LAUNCHES;
+    // launches since the last look at the (cumulative) counters belong to the old scene
+    ctx->box_rebase = ctx->box_probe_used;
     return RN_OK;
+}
+
+int rn_scatter_settled(const rn_ctx *ctx) {
+    // no scatter launch copies its overflow counters out any more: the tile shape stays as it is
+    // until the next rn_scatter_reset / rn_set_options (what a captured step relies on)
+    return ctx && ctx->box_probe == 0 ? 1 : 0;
 }
 
 int64_t rn_slab_boxes_size(const rn_ctx *ctx, int64_t rows) {

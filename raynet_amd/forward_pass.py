@@ -30,6 +30,8 @@ sharded contiguously over the ranks; each rank scatters into its own zeroed
 accumulator and one all-reduce (RCCL) per BP iteration merges them before the
 prior is added once.
 """
+import sys
+
 import numpy as np
 import torch
 
@@ -61,6 +63,34 @@ def _dist():
     if dist.is_available() and dist.is_initialized():
         return dist, dist.get_rank(), dist.get_world_size()
     return None, 0, 1
+
+
+def _backend_of(dist):
+    """"nccl" (= RCCL), "gloo", ... of the default group; a stand-in object (tools/shard_proxy.py)
+    answers for itself."""
+    try:
+        return str(dist.get_backend())
+    except Exception:
+        return ""
+
+
+def map_owner(k, n_images, world, mode):
+    """Rank that assembles image k's depth map (PathOptions.gather): "owner" deals the images out
+    in contiguous blocks -- monotone in k, so a rank's depth rows are already ordered by
+    destination rank, what an all-to-all wants -- "rank0" gives rank 0 all of them."""
+    return (k * world) // n_images if mode == "owner" else 0
+
+
+def _all_to_all_rows(dist, out, inp, out_split, in_split):
+    """all_to_all_single over the ranks' depth rows.  RCCL moves device memory; a transport that
+    only takes host tensors (gloo, the functional tests with several ranks on one GPU) is staged
+    through the host."""
+    if inp.is_cuda and _backend_of(dist) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_split, in_split)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, out_split, in_split)
 
 
 def sweep_direction(H, W, images):
@@ -310,6 +340,8 @@ class RayNetForwardPass(ForwardPass):
         self.shard_alpha = None    # ... and the per-ray constant the cuts weighed rays with
         self._side_stream = self._copy_stream = None
         self._pass_complete = True
+        self.trace = None          # a list: eager passes bracket their exchanges with events (_mark)
+        self.captured = False      # whether the last pass was a graph replay
         self.ref_idx = -1
         self._ctx = None
         self._de = None
@@ -565,8 +597,8 @@ class RayNetForwardPass(ForwardPass):
         # the sharding.  The feature maps' ADDRESSES are not geometry: when only they moved
         # (the allocator placed recomputed maps elsewhere) the pointer table is refreshed.
         key = (id(scene), tuple(id(c) for c in cams), tuple(sorted(views_of.items())), tuple(refs),
-               H, W, M, N, gp.depth_planes, world, rank, opt.key(), self.rays_batch, str(dev),
-               self._prior())
+               H, W, M, N, gp.depth_planes, world, rank, dist is not None, opt.key(),
+               self.rays_batch, str(dev), self._prior())
         plan = self._plan
         if plan is not None and plan["key"] == key and not self._filter_out_rays:
             if plan["ptrs"] != ptrs:
@@ -658,18 +690,38 @@ class RayNetForwardPass(ForwardPass):
         return plan
 
     # -- where the maps land -------------------------------------------------------------------
-    def _epilogue_buffers(self, plan, refs, H, W, dev, world, collective):
+    def _host_set(self, V, HW, cuda):
+        """One set of pinned host maps and its ROOT arrays (one flat ndarray per image).  What a
+        pass yields are fresh views of the roots; every view (and every view of a view) keeps its
+        root alive and counted, which is how _maps_held sees a caller still holding one."""
+        h = torch.empty((V, HW), dtype=torch.float32, pin_memory=cuda)
+        return h, [h[k].numpy() for k in range(V)]
+
+    @staticmethod
+    def _root_counts(roots):
+        return [sys.getrefcount(a) for a in roots]
+
+    def _maps_held(self, plan, slot):
+        return any(c > plan["root_rc"] for c in self._root_counts(plan["host_root"][slot]))
+
+    def _epilogue_buffers(self, plan, refs, H, W, dev, world, rank, collective):
         """Plan-owned output side: per-image events, the device-side pixel-order maps, and TWO
-        sets of pinned host maps used alternately -- a pass allocates nothing.  The arrays a
-        pass yields are views of its set: they stay valid until the second-next pass over the
-        same plan (copy them to keep them longer; the reference's `.get()` hands out fresh
-        arrays, forward_pass.py:739-744)."""
+        sets of pinned host maps used alternately -- a pass allocates nothing.  What a pass
+        yields (PathOptions.maps): views of its set, valid until the second-next pass over the
+        same plan ("view"); fresh arrays like the reference's `.get()`, forward_pass.py:739-744
+        ("copy"); or views until a caller is SEEN to keep one across passes -- that caller keeps
+        the memory, the plan takes a new set and hands out copies from then on ("auto")."""
         if "host" in plan:
             return
         cuda = dev.type == "cuda"
         V, HW = len(refs), H * W
-        plan["host"] = [torch.empty((V, HW), dtype=torch.float32, pin_memory=cuda) for _ in range(2)]
-        plan["host_np"] = [[h[k].numpy().reshape(W, H).T for k in range(V)] for h in plan["host"]]
+        sets = [self._host_set(V, HW, cuda) for _ in range(2)]
+        plan["host"] = [a for a, _ in sets]
+        plan["host_root"] = [b for _, b in sets]
+        plan["root_rc"] = max(self._root_counts(plan["host_root"][0])) if V else 0
+        plan["copy_maps"] = self.options.maps == "copy"
+        plan["graphs"] = {}
+        plan["passes"] = 0
         if "maps_dev" not in plan:
             plan["maps_dev"] = torch.zeros((V, HW), dtype=torch.float32, device=dev)
         plan["wait_ev"] = [None] * V
@@ -677,49 +729,90 @@ class RayNetForwardPass(ForwardPass):
             plan["ev_ready"] = [torch.cuda.Event() for _ in range(V)]
             plan["ev_stitch"] = [torch.cuda.Event() for _ in range(V)]
             plan["ev_done"] = [torch.cuda.Event() for _ in range(V)]
+            plan["ev_all"] = torch.cuda.Event()
             if self._side_stream is None:
                 self._side_stream, self._copy_stream = _side_streams(dev)
         npad, lists, bounds = plan["npad"], plan["lists"], plan["bounds"]
+        gather = self.options.gather if collective else "all"
+        plan["owners"] = None if gather == "all" else [map_owner(k, V, world, gather) for k in range(V)]
         if not collective:
             # rows -> pixels: one index per image (rays that were filtered out stay 0)
             plan["pix"] = [lists[r].long() for r in refs] if (
                 plan["patch_rows"] or self._filter_out_rays) else None
-        else:
-            # per image: the ranks' row blocks side by side (+ one zero for pixels without a
-            # ray) and the index that puts them into pixel order
-            plan["gathered"] = [torch.zeros((world * npad + 1,), dtype=torch.float32, device=dev)
-                                for _ in range(V)]
-            stitch = []
-            for k, r in enumerate(refs):
-                src = torch.full((HW,), world * npad, dtype=torch.int64, device=dev)
-                rays, cuts = lists[r].long(), bounds[k]
-                for q in range(world):
-                    lo_q, hi_q = cuts[q], cuts[q + 1]
-                    src[rays[lo_q:hi_q]] = q * npad + torch.arange(hi_q - lo_q, dtype=torch.int64,
-                                                                   device=dev)
-                stitch.append(src)
-            plan["stitch"] = stitch
-            # (rn_stitch_rows: the same table as 32-bit indices -- stitch and copy in one launch)
-            plan["stitch32"] = [t.to(torch.int32) for t in stitch] if cuda else None
-            # groups of images that share ONE depth launch, ONE all-gather and ONE stitch launch
-            # (a group's rows are contiguous in the scene-wide buffers, its host maps too)
-            gsz = self.options.rank_group
-            plan["rank_groups"] = None
-            if cuda and gsz > 0 and HW % 4 == 0 and hasattr(self._ctx, "stitch_rows") and \
-                    plan["fast"] is not None:
-                groups = [(a, min(a + gsz, V)) for a in range(0, V, gsz)]
-                gathered, tables = [], []
-                for a, b in groups:
-                    blk = (b - a) * npad                      # one rank's rows of the group
-                    gathered.append(torch.zeros((world * blk + 1,), dtype=torch.float32, device=dev))
-                    idx = torch.empty(((b - a), HW), dtype=torch.int32, device=dev)
-                    for k in range(a, b):
-                        q, j = stitch[k] // npad, stitch[k] % npad        # (rank, row) per pixel
-                        at = q * blk + (k - a) * npad + j
-                        idx[k - a] = torch.where(stitch[k] == world * npad,
-                                                 torch.full_like(at, world * blk), at).to(torch.int32)
-                    tables.append(idx.reshape(-1))
-                plan["rank_groups"], plan["gathered_grp"], plan["stitch32_grp"] = groups, gathered, tables
+            return
+
+        def stitch_index(k, r):
+            """per pixel of image k: q * npad + row within rank q's block (world * npad: no ray)"""
+            src = torch.full((HW,), world * npad, dtype=torch.int64, device=dev)
+            rays, cuts = lists[r].long(), bounds[k]
+            for q in range(world):
+                lo_q, hi_q = cuts[q], cuts[q + 1]
+                src[rays[lo_q:hi_q]] = q * npad + torch.arange(hi_q - lo_q, dtype=torch.int64,
+                                                               device=dev)
+            return src
+
+        plan["a2a"] = None
+        owners = plan["owners"]
+        if owners is not None and cuda and HW % 4 == 0 and hasattr(self._ctx, "stitch_rows") and \
+                plan["fast"] is not None:
+            # Owner-only epilogue (the map is needed ONCE, forward_pass.py:739-744): ONE depth
+            # launch over all of the rank's rows, ONE all-to-all that takes every rank's rows of
+            # image k to k's owner (the owners are monotone in k, so plan["depth"] already is in
+            # destination order), and on an owner ONE rn_stitch_rows launch that puts its images
+            # into pixel order and writes the pinned host maps across PCIe itself.
+            mine = [k for k in range(V) if owners[k] == rank]
+            n_own = len(mine)
+            blk = n_own * npad                       # one source rank's rows of my images
+            recv = torch.zeros((world * blk + 1,), dtype=torch.float32, device=dev)
+            table = None
+            if n_own:
+                idx = torch.empty((n_own, HW), dtype=torch.int32, device=dev)
+                for j, k in enumerate(mine):
+                    st = stitch_index(k, refs[k])
+                    at = (st // npad) * blk + j * npad + st % npad
+                    idx[j] = torch.where(st == world * npad, torch.full_like(at, world * blk),
+                                         at).to(torch.int32)
+                table = idx.reshape(-1)
+            plan["a2a"] = dict(mine=mine, recv=recv, table=table, out_split=[blk] * world,
+                               in_split=[npad * sum(1 for o in owners if o == d)
+                                         for d in range(world)])
+            return
+        # every rank assembles every map (gather="all", and back ends without rn_stitch_rows).
+        # per image: the ranks' row blocks side by side (+ one zero for pixels without a
+        # ray) and the index that puts them into pixel order
+        plan["gathered"] = [torch.zeros((world * npad + 1,), dtype=torch.float32, device=dev)
+                            for _ in range(V)]
+        stitch = [stitch_index(k, r) for k, r in enumerate(refs)]
+        plan["stitch"] = stitch
+        # (rn_stitch_rows: the same table as 32-bit indices -- stitch and copy in one launch)
+        plan["stitch32"] = [t.to(torch.int32) for t in stitch] if cuda else None
+        # groups of images that share ONE depth launch, ONE all-gather and ONE stitch launch
+        # (a group's rows are contiguous in the scene-wide buffers, its host maps too)
+        gsz = self.options.rank_group
+        plan["rank_groups"] = None
+        if cuda and gsz > 0 and HW % 4 == 0 and hasattr(self._ctx, "stitch_rows") and \
+                plan["fast"] is not None:
+            groups = [(a, min(a + gsz, V)) for a in range(0, V, gsz)]
+            gathered, tables = [], []
+            for a, b in groups:
+                blk = (b - a) * npad                      # one rank's rows of the group
+                gathered.append(torch.zeros((world * blk + 1,), dtype=torch.float32, device=dev))
+                idx = torch.empty(((b - a), HW), dtype=torch.int32, device=dev)
+                for k in range(a, b):
+                    q, j = stitch[k] // npad, stitch[k] % npad        # (rank, row) per pixel
+                    at = q * blk + (k - a) * npad + j
+                    idx[k - a] = torch.where(stitch[k] == world * npad,
+                                             torch.full_like(at, world * blk), at).to(torch.int32)
+                tables.append(idx.reshape(-1))
+            plan["rank_groups"], plan["gathered_grp"], plan["stitch32_grp"] = groups, gathered, tables
+
+    def _mark(self, name, begin):
+        """bench.py --gpus N: a pair of events around every exchange of an eager pass
+        (self.trace = []); nothing otherwise."""
+        if self.trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.trace.append((name, begin, ev))
 
     def _emit_image(self, plan, k, st, dist, world, slot):
         """Image k's depth rows (just enqueued on the current stream) -> pixel order -> pinned
@@ -735,7 +828,9 @@ class RayNetForwardPass(ForwardPass):
             side.wait_event(plan["ev_ready"][k])
             if dist is not None:
                 g = plan["gathered"][k]
+                self._mark("gather", True)
                 dist.all_gather_into_tensor(g[:-1], rows)
+                self._mark("gather", False)
                 if plan.get("stitch32") is not None and hasattr(self._ctx, "stitch_rows") and \
                         host.data_ptr() % 16 == 0:
                     # pixel order AND the way to the host in one launch: the kernel writes the
@@ -779,7 +874,9 @@ class RayNetForwardPass(ForwardPass):
         fast = plan["fast"]
         if not plan["fixed"]:
             if dist is not None:
+                self._mark("exchange", True)
                 dist.all_reduce(plan["acc_b" if it & 1 else "acc_a"], op=dist.ReduceOp.SUM)
+                self._mark("exchange", False)
             return
         part = plan["acc_part"]
         out = plan["acc_b" if it & 1 else "acc_a"]
@@ -789,19 +886,25 @@ class RayNetForwardPass(ForwardPass):
             if "slab_i" not in plan:
                 plan["slab_i"] = torch.empty((slab,), dtype=torch.int64, device=part.device)
                 plan["slab_f"] = torch.empty((slab,), dtype=torch.float32, device=part.device)
+            self._mark("exchange", True)
             dist.reduce_scatter_tensor(plan["slab_i"], part, op=dist.ReduceOp.SUM)
             part.zero_()
             ctx.acc_combine_fixed_range(plan["slab_i"], plan["prior"], plan["slab_f"])
             dist.all_gather_into_tensor(out, plan["slab_f"])
+            self._mark("exchange", False)
             return
         if dist is not None:
+            self._mark("exchange", True)
             dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            self._mark("exchange", False)
         ctx.scene_run(fast, _lib.RN_RUN_COMBINE, it)
 
-    def _run_plan_path(self, plan, ctx, refs, dist, world):
+    def _run_plan_path(self, plan, ctx, refs, dist, world, slot, captured=False):
         """One pass as phases of the C plan (include/raynet_hip.h, rn_scene_run): 1 + T calls
-        for the K1 prefix and the T BP iterations, the exchange between them, then one depth
-        launch per image with its maps leaving under the next image's."""
+        for the K1 prefix and the T BP iterations, the exchange between them, then the depth
+        sweep and the maps' way to the host.  Eager, or -- `captured` -- recorded into a HIP graph
+        (then nothing here may be waited for by the host: the side streams join the capturing
+        stream at the end and the graph's owner records ONE event behind each replay)."""
         fast, T = plan["fast"], self.bp_iterations
         fixed = plan["fixed"]
         if T == 0:
@@ -816,7 +919,6 @@ class RayNetForwardPass(ForwardPass):
             self._exchange(plan, ctx, dist, world, it)
         final = plan["acc_b" if (T - 1) & 1 else "acc_a"]
         self._acc_flat, self._acc_bias = final, (0.0 if fixed else plan["prior"])
-        slot = plan["slot"] = plan["slot"] ^ 1
         per_image = plan["per_image"]
         V = len(refs)
         if plan["direct"]:
@@ -831,8 +933,29 @@ class RayNetForwardPass(ForwardPass):
                     ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, a)
                 plan["ev_ready"][a].record()
             self._emit_direct(plan, groups, slot)
-            return slot
-        if dist is not None and plan.get("rank_groups"):
+        elif dist is not None and plan.get("a2a") is not None:
+            # owner-only maps: ONE depth launch over all of this rank's rows, ONE all-to-all
+            # that takes image k's rows of every rank to k's owner, ONE stitch launch there
+            a2a = plan["a2a"]
+            ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, 0 | (V << 16))
+            plan["ev_ready"][0].record()
+            side = self._side_stream
+            with torch.cuda.stream(side):
+                side.wait_event(plan["ev_ready"][0])
+                self._mark("gather", True)
+                _all_to_all_rows(dist, a2a["recv"][:-1], plan["depth"], a2a["out_split"],
+                                 a2a["in_split"])
+                self._mark("gather", False)
+                mine = a2a["mine"]
+                if mine:
+                    HW = plan["maps_dev"].shape[1]
+                    host = plan["host"][slot].view(-1)
+                    ctx.stitch_rows(a2a["recv"], a2a["table"],
+                                    host[mine[0] * HW:(mine[-1] + 1) * HW])
+                plan["ev_done"][0].record()
+            for k in range(V):
+                plan["wait_ev"][k] = plan["ev_done"][0]
+        elif dist is not None and plan.get("rank_groups"):
             # a rank of several: every group of images is ONE depth launch (all of them enqueued
             # first: the GPU never waits for the host between them), then per group ONE
             # all-gather of the ranks' row blocks and ONE rn_stitch_rows launch that puts them
@@ -855,28 +978,42 @@ class RayNetForwardPass(ForwardPass):
                 with torch.cuda.stream(side):
                     side.wait_event(plan["ev_ready"][a])
                     g = plan["gathered_grp"][i]
+                    self._mark("gather", True)
                     dist.all_gather_into_tensor(g[:-1], plan["depth"][a * npad:b * npad])
+                    self._mark("gather", False)
                     ctx.stitch_rows(g, plan["stitch32_grp"][i], host[a * HW:b * HW])
                     plan["ev_done"][a].record()
                 for k in range(a, b):
                     plan["wait_ev"][k] = plan["ev_done"][a]
-            return slot
-        if dist is None and V >= 3 and self.options.depth_head:
+        elif dist is None and V >= 3 and self.options.depth_head:
             # one GPU: all images but the last decoded by ONE launch (no launch tails between
             # them), the last on its own -- long enough for the others' maps to leave under it.
-            # (A rank of several keeps one launch per image: pairs were measured slower there,
-            # 1.23 - 1.29 -> 1.26 - 1.32 ms per step of an eight-rank shard -- its tail is the
-            # exchange and copy of whatever the last launch covers.)
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, 0 | ((V - 1) << 16))
             for j in range(V - 1):
                 self._emit_image(plan, j, per_image[refs[j]], dist, world, slot)
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, V - 1)
             self._emit_image(plan, V - 1, per_image[refs[V - 1]], dist, world, slot)
-            return slot
-        for k, r in enumerate(refs):
-            ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, k)
-            self._emit_image(plan, k, per_image[r], dist, world, slot)
-        return slot
+        else:
+            for k, r in enumerate(refs):
+                ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, k)
+                self._emit_image(plan, k, per_image[r], dist, world, slot)
+        if captured:
+            cur = torch.cuda.current_stream(ctx.device)
+            cur.wait_stream(self._side_stream)
+            cur.wait_stream(self._copy_stream)
+
+    def _capturable(self, plan, ctx, dist):
+        """Whether this pass may be recorded into a HIP graph: a CUDA device, a transport whose
+        collectives are stream work (RCCL; gloo runs on the host), the scatter's adaptive tile
+        shape settled (its probe launches copy counters to the host, and the shape is baked into
+        the graph), nobody bracketing launches with events."""
+        if not (self.options.capture and ctx.device.type == "cuda" and hasattr(ctx, "scatter_settled")):
+            return False
+        if self.trace is not None or getattr(ctx, "prof_active", False):
+            return False
+        if dist is not None and not (getattr(dist, "capturable", False) or _backend_of(dist) == "nccl"):
+            return False
+        return plan["passes"] >= 2 and ctx.scatter_settled()
 
     # -- the resident schedule ------------------------------------------------------------------
     def _forward_pass_resident(self, scene, images_range):
@@ -918,23 +1055,71 @@ class RayNetForwardPass(ForwardPass):
         self._pass_complete = False
 
         if plan["fast"] is not None:
-            self._epilogue_buffers(plan, refs, H, W, dev, world, dist is not None)
-            slot = self._run_plan_path(plan, ctx, refs, dist, world)
+            self._epilogue_buffers(plan, refs, H, W, dev, world, rank, dist is not None)
+            V = len(refs)
+            # which pinned set this pass writes.  "view" / "auto": the two sets in turns, so that a
+            # pass's maps outlive the next pass; "auto" looks, before it overwrites a set, whether
+            # the caller still holds a map (or a view of one) of the pass before last -- then the
+            # caller keeps that memory, the plan takes ONE new set and yields copies from now on.
+            if plan["copy_maps"]:
+                slot = 0
+            else:
+                slot = plan["slot"] ^ 1
+                if self.options.maps == "auto" and self._maps_held(plan, slot):
+                    h, roots = self._host_set(V, H * W, dev.type == "cuda")
+                    plan["host"], plan["host_root"] = [h, None], [roots, None]
+                    plan["copy_maps"], plan["graphs"], slot = True, {}, 0
+            plan["slot"] = slot
+            # (a pass whose launches or exchanges are bracketed by events runs eagerly)
+            eager = self.trace is not None or getattr(ctx, "prof_active", False) or \
+                not self.options.capture
+            graph = None if eager else plan["graphs"].get(slot)
+            if graph is None and not eager and self._capturable(plan, ctx, dist):
+                # the whole step -- phases, exchanges, epilogue -- as ONE graph (per host set):
+                # no interpreter and no launch overhead between its launches from now on
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self._run_plan_path(plan, ctx, refs, dist, world, slot, captured=True)
+                    plan["graphs"][slot] = graph
+                except Exception as e:        # a transport / runtime that cannot be captured
+                    import warnings
+                    warnings.warn("raynet_amd: step capture failed (%s); eager schedule" % (e,))
+                    self.options = self.options.replace(capture=False)
+                    plan["graphs"], graph = {}, None
+                    torch.cuda.synchronize(dev)
+            if graph is not None:
+                graph.replay()
+                plan["ev_all"].record()
+                plan["wait_ev"] = [plan["ev_all"]] * V
+                T = self.bp_iterations
+                self._acc_flat = plan["acc_b" if (T - 1) & 1 else "acc_a"]
+                self._acc_bias = 0.0 if plan["fixed"] else plan["prior"]
+            else:
+                self._run_plan_path(plan, ctx, refs, dist, world, slot)
+            self.captured = graph is not None
+            plan["passes"] += 1
             for r in refs:
                 st = per_image[r]
                 self.messages.put(r, st["msgs"], st["rvc"])
                 self.voxel_count[r] = st["rvc"]
-            maps = plan["host_np"][slot]
+            roots = plan["host_root"][slot]
+            owners = plan["owners"]
+            copy = plan["copy_maps"]
             spin = self.options.spin_wait
             for k, r in enumerate(refs):
+                self.ref_idx = r
+                if owners is not None and owners[k] != rank:
+                    yield None             # another rank assembles this image (PathOptions.gather)
+                    continue
                 ev = plan["wait_ev"][k]
                 if spin:
                     while not ev.query():
                         pass
                 else:
                     ev.synchronize()
-                self.ref_idx = r
-                yield maps[k]
+                a = roots[k].copy() if copy else roots[k]
+                yield a.reshape(W, H).T
             self._pass_complete = True
             return
         for out in self._run_granular(scene, refs, bank, ctx, plan, dist, rank, world):
@@ -1144,10 +1329,16 @@ class RayNetForwardPass(ForwardPass):
             st = per_image[r]
             self.messages.put(r, st["msgs"], st["rvc"])
             self.voxel_count[r] = st["rvc"]
-        for r, host, done in pending:
+        # with a process group, image k's map is handed out by ONE rank (PathOptions.gather; this
+        # launch-by-launch path still moves every map to every rank: it is the fallback)
+        mode = self.options.gather if collective else "all"
+        for k, (r, host, done) in enumerate(pending):
             if done is not None:
                 done.synchronize()
             self.ref_idx = r
+            if mode != "all" and map_owner(k, V, world, mode) != rank:
+                yield None
+                continue
             yield host.numpy().reshape(W, H).T
 
     def _forward_pass_reference(self, scene, images_range):

@@ -181,6 +181,11 @@ class HipContext(object):
                                               ctypes.byref(ov)))
         return int(lv.value), int(ch.value), int(ov.value)
 
+    def scatter_settled(self):
+        """No scatter launch touches the host any more and the tile shape stays as it is
+        (rn_scatter_settled): a step's launches may be recorded into a HIP graph."""
+        return bool(self.lib.rn_scatter_settled(self._h))
+
     # resident accumulators are 4x4x4-bricked (include/raynet_hip.h); the reference's
     # [gx][gy][gz] view is produced / consumed through these two
     def acc_size(self):
@@ -299,11 +304,13 @@ class HipContext(object):
                 mask |= 1 << ids[name]
         self._check(self.lib.rn_prof_select(self._h, mask))
         self._prof_cap = capacity
+        self.prof_active = True       # (event pairs around launches: such a pass is not captured)
         self._check(self.lib.rn_prof_begin(self._h, capacity))
 
     def prof_end(self):
         """-> list of (kernel name, n_rays, milliseconds), one per launch."""
         cap = self._prof_cap
+        self.prof_active = False
         ids = (ctypes.c_int32 * cap)()
         rays = (ctypes.c_int32 * cap)()
         ms = (ctypes.c_float * cap)()

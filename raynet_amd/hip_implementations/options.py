@@ -42,6 +42,14 @@ class PathOptions:
     #                                   stitch of a rank (the last group takes the rest); 0: the
     #                                   per-image exchange through index_select and a copy
     spin_wait: bool = False           # poll the maps' events instead of blocking on them
+    capture: bool = True              # the plan path's whole step (phases, exchanges, epilogue) as ONE
+    #                                   captured HIP graph per plan, replayed per pass: no interpreter and
+    #                                   no launch overhead between the launches (RCCL collectives are
+    #                                   captured with it; other transports keep the eager schedule)
+    maps: str = "auto"                # what a pass yields: "view" = views of the plan's pinned host maps
+    #                                   (valid until the second-next pass), "copy" = fresh arrays like the
+    #                                   reference's .get() (forward_pass.py:739-744), "auto" = views until
+    #                                   a caller is seen to keep one across passes, copies from then on
     # ---- memory ---------------------------------------------------------------------------
     resident_gb: float = 0.0          # HBM budget of the resident schedule; 0: 90 % of what is free
     # ---- multi-GPU ------------------------------------------------------------------------
@@ -51,6 +59,13 @@ class PathOptions:
     #                                       count; None: derived from the shape (shard_alpha_for)
     exchange: str = "allreduce"       # deterministic mode only: "reduce_scatter" = int64 reduce-scatter,
     #                                   combine on the rank's slab, float all-gather (3/4 of the bytes)
+    gather: str = "owner"             # with a process group, who assembles image k's map: "owner" = ONE
+    #                                   rank (k * world // images; the others yield None for it), "rank0",
+    #                                   or "all" = every rank every map (all-gather + stitch + host copy
+    #                                   on all of them: round 3's epilogue)
+    exchange_pieces: int = 1          # a BP iteration's rows in this many image groups, each group's
+    #                                   partial sums all-reduced on a side stream under the next group's
+    #                                   kernels (K x the bytes on the wire)
     # ---- the context's own options (rn_options in include/raynet_hip.h) ---------------------
     scatter_mode: int = -1            # -1 by row layout, 0 slab scatter, 2 LDS-box scatter
     box_level: int = 0                # tile shape the adaptive box scatter starts from
@@ -69,6 +84,10 @@ class PathOptions:
         "RAYNET_DIRECT_MAPS": ("direct_maps", _flag),
         "RAYNET_RANK_GROUP": ("rank_group", int),
         "RAYNET_SPIN_WAIT": ("spin_wait", _flag),
+        "RAYNET_CAPTURE": ("capture", _flag),
+        "RAYNET_MAPS": ("maps", str),
+        "RAYNET_GATHER": ("gather", str),
+        "RAYNET_EXCHANGE_PIECES": ("exchange_pieces", int),
         "RAYNET_RESIDENT_GB": ("resident_gb", float),
         "RAYNET_DETERMINISTIC": ("deterministic", _flag),
         "RAYNET_SHARD": ("shard", str),
@@ -90,6 +109,9 @@ class PathOptions:
         assert self.scatter_mode in (-1, 0, 2) and self.box_level in (0, 1, 2)
         assert self.overlap in (0, 1, 2)
         assert self.rank_group >= 0
+        assert self.maps in ("auto", "copy", "view"), self.maps
+        assert self.gather in ("owner", "rank0", "all"), self.gather
+        assert self.exchange_pieces >= 1
 
     @classmethod
     def from_env(cls, environ=None, **overrides):

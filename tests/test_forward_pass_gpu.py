@@ -251,7 +251,7 @@ def test_config1_restrepo_cameras(torch, oracle_mod):
         assert _depth_close(depths[r], depth.reshape(W, H).T, S_new, W, H) <= 0.02
 
 
-def _rank_main(rank, world, port, out_dir, deterministic=False):
+def _rank_main(rank, world, port, out_dir, deterministic=False, gather="all"):
     import os
     import sys
     import torch
@@ -266,11 +266,21 @@ def _rank_main(rank, world, port, out_dir, deterministic=False):
                                 world_size=world)
     H, W = 48, 64
     scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    from raynet_amd.forward_pass import map_owner
+    from raynet_amd.hip_implementations.options import PathOptions
     fp = get_forward_pass_factory("raynet")(bank, _gp(32, 192, (64, 64, 64)), "sample_in_bbox",
-                                            (H, W), 0, deterministic=deterministic)
+                                            (H, W), 0, deterministic=deterministic,
+                                            options=PathOptions.from_env(gather=gather))
     depths = list(fp.forward_pass(scene, (0, 5, 1)))
+    if world > 1 and gather != "all":
+        # image k's map is handed out by its owner only; the others get None for it
+        owned = np.array([map_owner(k, 5, world, gather) == rank for k in range(5)])
+        assert [d is not None for d in depths] == owned.tolist()
+        depths = [d if d is not None else np.zeros((H, W), np.float32) for d in depths]
+    else:
+        owned = np.ones(5, bool)
     np.savez(os.path.join(out_dir, "%sw%d_r%d.npz" % ("d" if deterministic else "", world, rank)),
-             depth=np.stack(depths), acc=fp.accumulator.cpu().numpy(),
+             depth=np.stack(depths), owned=owned, acc=fp.accumulator.cpu().numpy(),
              rows=np.array([len(fp.ray_index[r]) for r in range(5)]),
              balance=np.array(fp.shard_balance if fp.shard_balance is not None else []),
              alpha=np.float64(fp.shard_alpha if fp.shard_alpha is not None else 0.0))
@@ -287,8 +297,9 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_sharded_ranks_on_real_kernels(torch, tmp_path, world):
+@pytest.mark.parametrize("world,gather", [(2, "owner"), (4, "owner"), (8, "owner"), (8, "all"),
+                                          (4, "rank0"), (2, "all")])
+def test_sharded_ranks_on_real_kernels(torch, tmp_path, world, gather):
     """2 / 4 / 8 ranks (gloo, all on cuda:0 -- RCCL needs one GPU per rank) run the real HIP
     kernels on their voxel-balanced ray shards; the merged accumulator and depth maps equal
     the single-rank run (prior counted once) and are the same on every rank."""
@@ -300,7 +311,8 @@ def test_sharded_ranks_on_real_kernels(torch, tmp_path, world):
     procs[0].join(300)
     assert procs[0].exitcode == 0
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, out, False, gather))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -310,10 +322,24 @@ def test_sharded_ranks_on_real_kernels(torch, tmp_path, world):
     ranks = [np.load(out + "/w%d_r%d.npz" % (world, q)) for q in range(world)]
     r0 = ranks[0]
     for rq in ranks[1:]:
-        assert np.array_equal(r0["acc"], rq["acc"]) and np.array_equal(r0["depth"], rq["depth"])
+        assert np.array_equal(r0["acc"], rq["acc"])
         assert np.array_equal(r0["balance"], rq["balance"])
+    # every image's map is handed out: by every rank (gather="all", all of them equal), or by
+    # exactly one (the owner; PathOptions.gather)
+    owned = np.stack([rq["owned"] for rq in ranks])                         # [world, images]
+    assert np.all(owned.sum(0) == (world if gather == "all" else 1))
+    if gather == "rank0":
+        assert owned[0].all()
+    elif gather == "owner":
+        assert owned.sum(1).max() == -(-5 // world)                         # dealt out evenly
+    merged = np.zeros_like(one["depth"])
+    for q, rq in enumerate(ranks):
+        for k in np.where(rq["owned"])[0]:
+            if gather == "all" and q > 0:
+                assert np.array_equal(rq["depth"][k], merged[k])
+            merged[k] = rq["depth"][k]
     assert np.abs(one["acc"] - r0["acc"]).max() < 5e-4
-    assert (np.abs(one["depth"] - r0["depth"]) > 1e-4).mean() < 0.01
+    assert (np.abs(one["depth"] - merged) > 1e-4).mean() < 0.01
     # every ray owned once; what the cuts equalise is a rank's WEIGHT -- its traversed voxels
     # plus alpha x the mean count for every ray (the plane sweep costs the same for every ray;
     # alpha from the shape, options.shard_alpha_for: 0.16 N D / mean count) -- to 10 % here (cuts
@@ -366,6 +392,97 @@ def test_plan_path_equals_the_launch_by_launch_path(torch):
         assert np.abs(res[True, False][2] - res[False, False][2]).max() <= 1e-4
         assert (np.abs(res[True, False][0] - res[False, False][0]) > 1e-4).mean() < 0.01
         assert np.abs(res[True, False][1] - res[True, True][1]).max() <= 5e-4
+
+
+def test_captured_step_replays_the_eager_pass(torch):
+    """Once the scatter's adaptive tile shape has settled, a plan's whole step -- K1 prefix, BP
+    sweeps, scatters, depth launches, the maps' copies -- is recorded into ONE HIP graph per
+    pinned host set and replayed: the same bits as the eager passes (fixed-point mode), the
+    same accumulator view, and `capture=False` never captures."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.hip_implementations.options import PathOptions
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W = 48, 64
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(32, 192, (64, 64, 64))
+    cls = get_forward_pass_factory("raynet")
+    for T in (3, 2):
+        fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, bp_iterations=T,
+                 options=PathOptions(deterministic=True))
+        first = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+        acc = fp.accumulator.cpu().numpy()
+        assert not fp.captured
+        seen = []
+        for i in range(8):
+            d = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+            seen.append(fp.captured)
+            assert np.array_equal(d, first), (T, i)
+            assert np.array_equal(fp.accumulator.cpu().numpy(), acc)
+        assert seen[-1] and seen[-2] and len(fp._plan["graphs"]) == 2       # both host sets
+        msgs = fp.messages[1].cpu().numpy()
+        eager = cls(bank, gp, "sample_in_bbox", (H, W), 0, bp_iterations=T,
+                    options=PathOptions(deterministic=True, capture=False))
+        for i in range(7):
+            d = np.stack([m.copy() for m in eager.forward_pass(scene, (0, 5, 1))])
+        assert not eager.captured and np.array_equal(d, first)
+        assert np.array_equal(eager.messages[1].cpu().numpy(), msgs)
+
+
+def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
+    """PathOptions.maps.  "auto" (default): a pass yields views of plan-owned pinned memory
+    until a caller is seen to keep one across two later passes -- that caller keeps its
+    memory, the plan takes a new set and yields fresh arrays from then on (the reference hands
+    out fresh arrays from `.get()`, forward_pass.py:739-744).  "copy": fresh arrays always.
+    "view": the documented zero-copy lifetime (the second-next pass overwrites).  bp_iterations
+    is not part of the plan key, so passes with different T share one plan -- and differ."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.hip_implementations.options import PathOptions
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W = 48, 64
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(32, 192, (64, 64, 64))
+    cls = get_forward_pass_factory("raynet")
+
+    def run(fp, T):
+        fp.bp_iterations = T
+        return list(fp.forward_pass(scene, (0, 5, 1)))
+
+    truth = {}
+    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True, maps="copy"))
+    for T in (3, 1, 2):
+        truth[T] = np.stack(run(fp, T))
+    assert not np.array_equal(truth[3], truth[1])
+    a, b = run(fp, 3), run(fp, 1)
+    assert not any(np.shares_memory(x, y) for x in a for y in b)
+
+    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True))
+    a = run(fp, 3)
+    b = run(fp, 1)
+    assert not fp._plan["copy_maps"]
+    c = run(fp, 2)              # would land in a's pinned set: the plan sees `a` alive
+    assert fp._plan["copy_maps"]
+    assert np.array_equal(np.stack(a), truth[3]) and np.array_equal(np.stack(b), truth[1])
+    assert np.array_equal(np.stack(c), truth[2])
+    d = run(fp, 3)
+    assert np.array_equal(np.stack(c), truth[2]) and np.array_equal(np.stack(d), truth[3])
+    # a caller that lets go of the maps (bench.py) never pays for a copy
+    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True))
+    for T in (3, 1, 2, 3):
+        got = np.stack(run(fp, T))          # (np.stack copies; the views die here)
+        assert np.array_equal(got, truth[T])
+    assert not fp._plan["copy_maps"]
+    # a slice of a map keeps the whole map alive, and counted
+    keep = run(fp, 1)[2][5:9, 7:11]
+    run(fp, 2)
+    run(fp, 3)
+    assert fp._plan["copy_maps"] and np.array_equal(keep, truth[1][2][5:9, 7:11])
+
+    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True, maps="view"))
+    a = run(fp, 3)
+    b = run(fp, 1)
+    c = run(fp, 2)
+    assert all(np.shares_memory(x, y) for x, y in zip(a, c))       # the documented lifetime
+    assert np.array_equal(np.stack(a), truth[2]) and np.array_equal(np.stack(b), truth[1])
 
 
 def test_pixel_order_maps_straight_from_the_depth_sweep(torch):
@@ -545,8 +662,11 @@ def _nccl_single_main(port, out_dir):
     scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
     from raynet_amd.hip_implementations.options import PathOptions
     res = {}
-    for tag, opt in (("f", PathOptions()), ("d", PathOptions(deterministic=True)),
-                     ("rs", PathOptions(deterministic=True, exchange="reduce_scatter")),
+    for tag, opt in (("f", PathOptions(capture=False)), ("d", PathOptions(deterministic=True, capture=False)),
+                     ("rs", PathOptions(deterministic=True, exchange="reduce_scatter", capture=False)),
+                     ("all", PathOptions(deterministic=True, gather="all", capture=False)),
+                     ("cap", PathOptions(deterministic=True)),
+                     ("capall", PathOptions(deterministic=True, gather="all")),
                      ("g", PathOptions(plan_path=False))):
         fp = get_forward_pass_factory("raynet")(bank, _gp(32, 192, (64, 64, 64)), "sample_in_bbox",
                                                 (H, W), 0, options=opt)
@@ -554,10 +674,21 @@ def _nccl_single_main(port, out_dir):
         assert (fp._plan["fast"] is not None) == opt.plan_path
         if tag == "rs":
             assert "slab_i" in fp._plan       # the reduce-scatter / all-gather pair did run
+        if opt.plan_path:
+            assert (fp._plan["a2a"] is not None) == (opt.gather != "all")   # owner-only epilogue
+        if tag.startswith("cap"):
+            # the step as ONE captured graph, RCCL's collectives in it: once the scatter's
+            # tile shape has settled every pass is a replay -- with the first pass's bits
+            for _ in range(7):
+                again = [m.copy() for m in fp.forward_pass(scene, (0, 5, 1))]
+            assert fp.captured, "the step was never captured under RCCL"
+            assert all(np.array_equal(a, b) for a, b in zip(again, depths))
         res[tag] = (np.stack(depths), fp.accumulator.cpu().numpy())
     np.savez(os.path.join(out_dir, "nccl.npz"), depth=res["f"][0], acc=res["f"][1],
              depth_fixed=res["d"][0], acc_fixed=res["d"][1], depth_rs=res["rs"][0],
-             acc_rs=res["rs"][1], depth_granular=res["g"][0], acc_granular=res["g"][1])
+             acc_rs=res["rs"][1], depth_granular=res["g"][0], acc_granular=res["g"][1],
+             depth_all=res["all"][0], acc_all=res["all"][1], depth_cap=res["cap"][0],
+             acc_cap=res["cap"][1], depth_capall=res["capall"][0], acc_capall=res["capall"][1])
     dist.destroy_process_group()
 
 
@@ -588,6 +719,9 @@ def test_rccl_code_path_in_a_one_rank_world(torch, tmp_path):
     assert np.array_equal(got["depth_fixed"], ref_d["depth"])
     assert np.array_equal(got["acc_rs"], ref_d["acc"])             # ... whatever the exchange
     assert np.array_equal(got["depth_rs"], ref_d["depth"])
+    for tag in ("all", "cap", "capall"):                           # ... the epilogue, eager or captured
+        assert np.array_equal(got["acc_" + tag], ref_d["acc"]), tag
+        assert np.array_equal(got["depth_" + tag], ref_d["depth"]), tag
     assert np.abs(got["acc_granular"] - ref["acc"]).max() < 5e-4
     assert (np.abs(got["depth_granular"] - ref["depth"]) > 1e-4).mean() < 0.01
 

@@ -35,8 +35,19 @@ class FakeDist(object):
     def __init__(self, world):
         self.world = world
 
+    capturable = True       # the stand-ins are stream work: the step is captured like RCCL's would be
+
+    def get_backend(self):
+        return "fake"
+
     def all_reduce(self, t, op=None):
         pass
+
+    def all_to_all_single(self, out, inp, out_split=None, in_split=None):
+        # this rank receives out_split[q] rows from every rank q: its own block, from itself
+        n = out_split[0]
+        if n:
+            out.view(self.world, n).copy_(inp[:n].view(1, n).expand(self.world, n))
 
     def reduce_scatter_tensor(self, out, inp, op=None):
         out.copy_(inp.view(self.world, -1)[0])
@@ -54,11 +65,13 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     for rank in (range(world) if os.environ.get("ALL_RANKS") else sorted({0, world // 2})):
         fake = FakeDist(world)
         F._dist = (lambda f=fake, r=rank, w=world: (f, r, w)) if world > 1 else (lambda: (None, 0, 1))
-        fp = F.get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0)
+        from raynet_amd.hip_implementations.options import PathOptions
+        fp = F.get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0,
+                                                  options=PathOptions.from_env())
         def step():
             for _ in fp.forward_pass(scene, (0, V, 1)):
                 pass
-        for _ in range(3):
+        for _ in range(int(os.environ.get("WARM", "8"))):      # (the step is captured once the scatter has settled)
             step()
         import gc
         gc.collect()
@@ -90,8 +103,8 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
                 print("   %-10s start %8.3f  gap %7.3f  dur %7.3f" % (name, st, st - end_prev, k_ms))
                 end_prev = st + k_ms
         res[(world, rank)] = ms
-        print("world %d rank %d: %.3f ms/step  kernels %.3f  (%s)  scatter level/chunks/overflowed %s" % (
-            world, rank, ms, sum(fam.values()), " ".join("%s=%.3f" % kv for kv in sorted(fam.items())),
+        print("world %d rank %d%s: %.3f ms/step  kernels %.3f  (%s)  scatter level/chunks/overflowed %s" % (
+            world, rank, " (captured)" if fp.captured else "", ms, sum(fam.values()), " ".join("%s=%.3f" % kv for kv in sorted(fam.items())),
             ctx.scatter_state()))
         if fp.shard_balance is not None and rank == 0:
             bal = np.array(fp.shard_balance, dtype=np.float64).sum(0)
