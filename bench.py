@@ -286,7 +286,33 @@ def main():
     by_family = timeline_shares(launches_all, list(getattr(ctx, "prof_starts", [])))
     dominant = max((k for k in by_family if k != "acc"), key=lambda k: by_family[k], default=None)
     only = [dominant] if (args.events == "dominant" and dominant) else None
-    ctx.prof_begin(capacity=64 * V * max(args.steps, 1) + 64, only=only)
+    # A captured step cannot be bracketed from outside: the dominant family's launches carry
+    # external event-record nodes INSIDE the graph instead (rn_prof_graph_*), re-recorded by
+    # every replay and read after each step on rank 0 (the rank that waits for image 0's map).
+    # The graphs are captured again with those nodes (untimed), one replay is checked for sane
+    # durations, and every rank takes the same decision; otherwise -- and with --events all --
+    # the timed region is eager with plain event pairs around the launches, as in round 3.
+    graph_mode = bool(fp.captured and only and hasattr(ctx, "prof_graph_read"))
+    if graph_mode:
+        fp.set_graph_events(only)
+        for _ in range(3):
+            step()
+        fence()
+        got = ctx.prof_graph_read()
+        sane = bool(fp.captured and got and all(0.0 < ms < 1e4 for _, _, ms in got))
+        if world > 1:
+            t = torch.tensor([1 if sane else 0], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            sane = bool(int(t.item()))
+        if not sane:
+            graph_mode = False
+            fp.set_graph_events(None)
+            fp.options = fp.options.replace(capture=False)
+    elif fp.captured:
+        fp.options = fp.options.replace(capture=False)      # --events all: eager, every launch bracketed
+    if not graph_mode:
+        ctx.prof_begin(capacity=64 * V * max(args.steps, 1) + 64, only=only)
+    graph_launches = []
     # the interpreter's cyclic garbage collector is a property of the host process, not of the
     # path: a generation-2 collection of a process that has imported torch pauses it for ~40 ms,
     # once every ~20 passes (tools/step_jitter.py) -- five steps' worth landing in whichever
@@ -297,10 +323,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if graph_mode and rank == 0:
+            graph_launches.extend(ctx.prof_graph_read())
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    launches = ctx.prof_end()
+    launches = graph_launches if graph_mode else ctx.prof_end()
     ranks_report = None
     if world > 1:
         # what every rank saw: its own wall time for the K steps, its kernel families' sums and
@@ -550,7 +578,10 @@ def main():
             "cpu_baseline": cpu,
             "kernels": kernels,
             "ranks": ranks_report,
-            "step_capture": {"captured": bool(fp.captured), "extra_warmup_steps": extra_warmup},
+            "step_capture": {"captured": bool(fp.captured), "extra_warmup_steps": extra_warmup,
+                             "timed_region": "graph replays; the dominant family's launches carry "
+                                             "external event-record nodes, read after every step"
+                             if graph_mode else "eager launches bracketed by event pairs"},
             "kernel_events": {"breakdown_steps_untimed": breakdown_steps,
                               "timed_region": "all launches" if only is None else
                               "launches of %s only" % dominant},

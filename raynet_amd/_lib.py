@@ -152,6 +152,9 @@ SIGNATURES = {
     "rn_consistency_tau": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "rn_nearest_neighbors": [_P, _I, _P, _I, _P, _P, _P, _P],
     "rn_prof_offsets": [_P, _P],
+    "rn_prof_graph_begin": [_P, ctypes.c_uint32],
+    "rn_prof_graph_end": [_P],
+    "rn_prof_graph_read": [_P, ctypes.POINTER(_I), _P, _P, _P],
     "rn_selftest_arith": [_P, _I, _P, _P, _P],
     "rn_selftest_quotient": [_P, _I, _P, _P, _P, _P],
     "rn_selftest_mapping": [_P, _I, _P, _P, _P, _P, _P],

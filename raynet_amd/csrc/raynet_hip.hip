@@ -278,6 +278,11 @@ struct rn_ctx {
     int prof_cap, prof_n;
     hipEvent_t *prof_ev;      // 2 * prof_cap
     int32_t *prof_id, *prof_rays;
+    // launches recorded into a HIP graph (rn_prof_graph_*): external event-record nodes
+    uint32_t gprof_mask;
+    int gprof_n;
+    hipEvent_t gprof_ev[2 * 64];
+    int32_t gprof_id[64], gprof_rays[64];
     char err[512];
 };
 
@@ -285,17 +290,32 @@ struct rn_ctx {
 struct ProfScope {
     rn_ctx *c;
     hipStream_t st;
-    int slot;
-    ProfScope(rn_ctx *ctx, int id, int n_rays, hipStream_t s) : c(ctx), st(s), slot(-1) {
+    int slot, gslot;
+    ProfScope(rn_ctx *ctx, int id, int n_rays, hipStream_t s) : c(ctx), st(s), slot(-1), gslot(-1) {
         if (c->prof_on && ((c->prof_mask >> id) & 1u) && c->prof_n < c->prof_cap) {
             slot = c->prof_n++;
             c->prof_id[slot] = id;
             c->prof_rays[slot] = n_rays;
             (void)hipEventRecord(c->prof_ev[2 * slot], st);
+        } else if (((c->gprof_mask >> id) & 1u) && c->gprof_n < 64) {
+            // a launch that is being CAPTURED: external event-record nodes travel with it
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+                const int g = c->gprof_n;
+                if (!c->gprof_ev[2 * g] && (hipEventCreate(&c->gprof_ev[2 * g]) != hipSuccess ||
+                                            hipEventCreate(&c->gprof_ev[2 * g + 1]) != hipSuccess))
+                    return;
+                gslot = c->gprof_n++;
+                c->gprof_id[gslot] = id;
+                c->gprof_rays[gslot] = n_rays;
+                (void)hipEventRecordWithFlags(c->gprof_ev[2 * gslot], st, hipEventRecordExternal);
+            }
         }
     }
     ~ProfScope() {
         if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], st);
+        if (gslot >= 0)
+            (void)hipEventRecordWithFlags(c->gprof_ev[2 * gslot + 1], st, hipEventRecordExternal);
     }
 };
 
@@ -773,6 +793,8 @@ void rn_destroy(rn_ctx *ctx) {
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->aux) hipStreamDestroy(ctx->aux);
+    for (int i = 0; i < 2 * 64; i++)
+        if (ctx->gprof_ev[i]) hipEventDestroy(ctx->gprof_ev[i]);
     for (int i = 0; i < 2 * ctx->prof_cap; i++) hipEventDestroy(ctx->prof_ev[i]);
     delete[] ctx->prof_ev;
     delete[] ctx->prof_id;
@@ -1541,6 +1563,34 @@ int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *
         if (n_rays_host) n_rays_host[i] = ctx->prof_rays[i];
     }
     *count = n;
+    return RN_OK;
+}
+
+int rn_prof_graph_begin(rn_ctx *ctx, uint32_t kernel_mask) {
+    if (!ctx) return RN_ERR_INVALID;
+    ctx->gprof_mask = kernel_mask;
+    ctx->gprof_n = 0;
+    return RN_OK;
+}
+
+int rn_prof_graph_end(rn_ctx *ctx) {
+    if (!ctx) return RN_ERR_INVALID;
+    ctx->gprof_mask = 0;
+    return RN_OK;
+}
+
+int rn_prof_graph_read(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host,
+                       int32_t *n_rays_host, float *ms_host) {
+    if (!ctx || !count) return fail(ctx, RN_ERR_INVALID, "bad argument");
+    for (int i = 0; i < ctx->gprof_n; i++) {
+        float ms = 0.0f;
+        RN_HIP(ctx, hipEventSynchronize(ctx->gprof_ev[2 * i + 1]));
+        RN_HIP(ctx, hipEventElapsedTime(&ms, ctx->gprof_ev[2 * i], ctx->gprof_ev[2 * i + 1]));
+        if (ms_host) ms_host[i] = ms;
+        if (kernel_ids_host) kernel_ids_host[i] = ctx->gprof_id[i];
+        if (n_rays_host) n_rays_host[i] = ctx->gprof_rays[i];
+    }
+    *count = ctx->gprof_n;
     return RN_OK;
 }
 

@@ -342,6 +342,7 @@ class RayNetForwardPass(ForwardPass):
         self._pass_complete = True
         self.trace = None          # a list: eager passes bracket their exchanges with events (_mark)
         self.captured = False      # whether the last pass was a graph replay
+        self.graph_events = None   # kernel families whose captured launches carry event nodes
         self.ref_idx = -1
         self._ctx = None
         self._de = None
@@ -378,6 +379,15 @@ class RayNetForwardPass(ForwardPass):
     @accumulator.setter
     def accumulator(self, value):
         self._acc_grid, self._acc_flat, self._acc_bias = value, None, 0.0
+
+    def set_graph_events(self, families):
+        """Kernel families (HipContext.KERNEL_NAMES) whose launches are bracketed by external
+        event-record nodes INSIDE the captured step (rn_prof_graph_*): every replay re-records
+        them, `ctx.prof_graph_read()` after a completed pass returns that pass's durations.
+        Graphs captured before are dropped (the next passes capture again)."""
+        self.graph_events = list(families) if families else None
+        if self._plan is not None and "graphs" in self._plan:
+            self._plan["graphs"] = {}
 
     # -- helpers -----------------------------------------------------------
     def _context(self, scene, F):
@@ -1079,8 +1089,12 @@ class RayNetForwardPass(ForwardPass):
                 # no interpreter and no launch overhead between its launches from now on
                 try:
                     graph = torch.cuda.CUDAGraph()
+                    if self.graph_events and hasattr(ctx, "prof_graph_begin"):
+                        ctx.prof_graph_begin(self.graph_events)
                     with torch.cuda.graph(graph):
                         self._run_plan_path(plan, ctx, refs, dist, world, slot, captured=True)
+                    if self.graph_events and hasattr(ctx, "prof_graph_end"):
+                        ctx.prof_graph_end()
                     plan["graphs"][slot] = graph
                 except Exception as e:        # a transport / runtime that cannot be captured
                     import warnings

@@ -322,6 +322,26 @@ class HipContext(object):
         return [(self.KERNEL_NAMES.get(ids[i], str(ids[i])), int(rays[i]), float(ms[i]))
                 for i in range(n.value)]
 
+    def prof_graph_begin(self, only):
+        """Launches of the named families CAPTURED from now on carry external event-record
+        nodes (rn_prof_graph_begin); prof_graph_end() stops that, prof_graph_read() returns the
+        last completed replay's (family, n_rays, ms) per captured launch."""
+        ids = {v: k for k, v in self.KERNEL_NAMES.items()}
+        mask = 0
+        for name in only:
+            mask |= 1 << ids[name]
+        self._check(self.lib.rn_prof_graph_begin(self._h, mask))
+
+    def prof_graph_end(self):
+        self._check(self.lib.rn_prof_graph_end(self._h))
+
+    def prof_graph_read(self):
+        ids, rays, ms = (ctypes.c_int32 * 64)(), (ctypes.c_int32 * 64)(), (ctypes.c_float * 64)()
+        n = ctypes.c_int32()
+        self._check(self.lib.rn_prof_graph_read(self._h, ctypes.byref(n), ids, rays, ms))
+        return [(self.KERNEL_NAMES.get(ids[i], str(ids[i])), int(rays[i]), float(ms[i]))
+                for i in range(n.value)]
+
     def selftest_arith(self, a, out):
         """out[2][n]: roundf(a), round_half_away(a) (tests only)."""
         self._check(self.lib.rn_selftest_arith(self._h, a.numel(), _ptr(a), _ptr(out), _stream()))

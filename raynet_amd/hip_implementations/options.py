@@ -147,7 +147,9 @@ class PathOptions:
     def key(self):
         k = self.__dict__.get("_key")
         if k is None:
-            k = tuple(sorted(self.as_dict().items()))
+            # (what a plan's buffers and tables depend on: not how its passes are issued / awaited)
+            k = tuple(sorted((n, v) for n, v in self.as_dict().items()
+                             if n not in ("capture", "spin_wait")))
             object.__setattr__(self, "_key", k)
         return k
 
