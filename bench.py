@@ -276,7 +276,8 @@ def main():
     # (a dozen scatter launches after the plan was built): the remaining untimed passes until
     # then -- the same number on every rank, the criterion counts launches
     extra_warmup = 0
-    while fp.options.capture and not fp.captured and extra_warmup < 8:
+    while fp.options.capture != "off" and (world > 1 or fp.options.capture == "on") and \
+            not fp.captured and extra_warmup < 8:
         step()
         extra_warmup += 1
     # Which family dominates: by its SHARE of the timeline, not by the sum of its launches'
@@ -286,33 +287,16 @@ def main():
     by_family = timeline_shares(launches_all, list(getattr(ctx, "prof_starts", [])))
     dominant = max((k for k in by_family if k != "acc"), key=lambda k: by_family[k], default=None)
     only = [dominant] if (args.events == "dominant" and dominant) else None
-    # A captured step cannot be bracketed from outside: the dominant family's launches carry
-    # external event-record nodes INSIDE the graph instead (rn_prof_graph_*), re-recorded by
-    # every replay and read after each step on rank 0 (the rank that waits for image 0's map).
-    # The graphs are captured again with those nodes (untimed), one replay is checked for sane
-    # durations, and every rank takes the same decision; otherwise -- and with --events all --
-    # the timed region is eager with plain event pairs around the launches, as in round 3.
-    graph_mode = bool(fp.captured and only and hasattr(ctx, "prof_graph_read"))
-    if graph_mode:
-        fp.set_graph_events(only)
-        for _ in range(3):
-            step()
-        fence()
-        got = ctx.prof_graph_read()
-        sane = bool(fp.captured and got and all(0.0 < ms < 1e4 for _, _, ms in got))
-        if world > 1:
-            t = torch.tensor([1 if sane else 0], dtype=torch.int64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            sane = bool(int(t.item()))
-        if not sane:
-            graph_mode = False
-            fp.set_graph_events(None)
-            fp.options = fp.options.replace(capture=False)
-    elif fp.captured:
-        fp.options = fp.options.replace(capture=False)      # --events all: eager, every launch bracketed
+    # A captured step cannot be bracketed from outside (and the HIP runtime torch ships does not
+    # honour external event-record nodes inside a graph: tried, hipEventElapsedTime refuses
+    # them).  One GPU: the step is not captured (PathOptions.capture "auto": nothing to gain, the
+    # host runs ahead of a 6.7 ms step) and the timed region brackets the dominant family's
+    # launches with plain event pairs, as before.  N > 1: the timed region is graph replays;
+    # the per-launch durations of every family -- the roofline block's too -- are those of the
+    # untimed, eager breakdown steps just before it (roofline.duration_source says which).
+    graph_mode = bool(fp.captured)
     if not graph_mode:
         ctx.prof_begin(capacity=64 * V * max(args.steps, 1) + 64, only=only)
-    graph_launches = []
     # the interpreter's cyclic garbage collector is a property of the host process, not of the
     # path: a generation-2 collection of a process that has imported torch pauses it for ~40 ms,
     # once every ~20 passes (tools/step_jitter.py) -- five steps' worth landing in whichever
@@ -323,12 +307,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if graph_mode and rank == 0:
-            graph_launches.extend(ctx.prof_graph_read())
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    launches = graph_launches if graph_mode else ctx.prof_end()
+    launches = [l for l in launches_all if only is None or l[0] in only] if graph_mode \
+        else ctx.prof_end()
     ranks_report = None
     if world > 1:
         # what every rank saw: its own wall time for the K steps, its kernel families' sums and
@@ -450,7 +433,12 @@ def main():
                                  "lists / columns / messages",
                             bytes_per_launch=int(d["strict"] / d["launches"]),
                             achieved=round(strict, 1), frac=round(strict / HBM_PEAK_GBS, 4)),
-                        writes_first_messages=bool(folded) if dominant == "sweep_map" else None)
+                        writes_first_messages=bool(folded) if dominant == "sweep_map" else None,
+                        duration_source="HIP event pairs around the kernel's launches in the timed "
+                                        "region" if not graph_mode else
+                                        "HIP event pairs around the kernel's launches in the %d untimed "
+                                        "eager steps before the timed region (which replays a captured "
+                                        "graph)" % breakdown_steps)
     kernels = {k: dict(total_ms_per_step=round(v["ms"] / breakdown_steps, 3),
                        timeline_share_ms_per_step=round(by_family.get(k, 0.0) / breakdown_steps, 3),
                        launches_per_step=v["launches"] / breakdown_steps,
@@ -579,8 +567,8 @@ def main():
             "kernels": kernels,
             "ranks": ranks_report,
             "step_capture": {"captured": bool(fp.captured), "extra_warmup_steps": extra_warmup,
-                             "timed_region": "graph replays; the dominant family's launches carry "
-                                             "external event-record nodes, read after every step"
+                             "timed_region": "graph replays (launch durations: the eager breakdown "
+                                             "steps before it)"
                              if graph_mode else "eager launches bracketed by event pairs"},
             "kernel_events": {"breakdown_steps_untimed": breakdown_steps,
                               "timed_region": "all launches" if only is None else

@@ -367,6 +367,10 @@ typedef struct {
                                       no reordering pass behind the sweep.  Entries no ray of the
                                       list maps to are left as they are                      */
     int64_t depth_image_stride;    /* floats between two images' maps (>= max ray index + 1) */
+    int32_t sweep_xcd_chunk;       /* plane sweep: consecutive wavefronts (entries of `order`) in
+                                      groups of this many RAYS per XCD, the groups dealt round the
+                                      8 XCDs -- one group is what an XCD's private L2 sees side by
+                                      side (a multiple of 4; 0: the library's default, 2048)    */
 } rn_scene_plan;
 typedef enum {
     RN_RUN_PREPARE = 1,   /* traversal + plane sweep + mapping of all images (rn_scene_prepare_all) */
@@ -417,16 +421,6 @@ int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *
 /* after rn_prof_end: start of every recorded launch, in ms after the first one's start
  * (the gaps between launches = what the host side costs; tools/timeline.py) */
 int rn_prof_offsets(rn_ctx *ctx, float *start_ms_host);
-/* The same for launches recorded into a HIP GRAPH (stream capture): between rn_prof_graph_begin
- * and rn_prof_graph_end every launch of the selected families (bit 1 << rn_kernel_id) made on a
- * CAPTURING stream gets a pair of EXTERNAL event-record nodes (hipEventRecordExternal) with it;
- * every replay of the graph records them again, and rn_prof_graph_read -- after the replay has
- * completed -- returns the durations of that replay, per captured launch.  At most 64 launches
- * per capture; the events belong to the context and are reused by the next capture. */
-int rn_prof_graph_begin(rn_ctx *ctx, uint32_t kernel_mask);
-int rn_prof_graph_end(rn_ctx *ctx);
-int rn_prof_graph_read(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host,
-                       int32_t *n_rays_host, float *ms_host);
 
 /* Self-test of the exact arithmetic shortcut of the index maps (raynet_kernels.h:
  * round_half_away), for tests/: out is [2][n] -- roundf(a), round_half_away(a). */

@@ -82,6 +82,7 @@ class ScenePlan(ctypes.Structure):
         ("acc", ctypes.c_void_p * 2), ("acc_fixed", ctypes.c_void_p),
         ("depth", ctypes.c_void_p), ("prior", ctypes.c_float), ("row_layout", ctypes.c_int32),
         ("depth_image", ctypes.c_void_p), ("depth_image_stride", ctypes.c_int64),
+        ("sweep_xcd_chunk", ctypes.c_int32),
     ]
 
 
@@ -152,9 +153,6 @@ SIGNATURES = {
     "rn_consistency_tau": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "rn_nearest_neighbors": [_P, _I, _P, _I, _P, _P, _P, _P],
     "rn_prof_offsets": [_P, _P],
-    "rn_prof_graph_begin": [_P, ctypes.c_uint32],
-    "rn_prof_graph_end": [_P],
-    "rn_prof_graph_read": [_P, ctypes.POINTER(_I), _P, _P, _P],
     "rn_selftest_arith": [_P, _I, _P, _P, _P],
     "rn_selftest_quotient": [_P, _I, _P, _P, _P, _P],
     "rn_selftest_mapping": [_P, _I, _P, _P, _P, _P, _P],

@@ -62,20 +62,29 @@ __device__ __forceinline__ int xcd_block(int b, int nblocks) {
     return start + pos;
 }
 
+// the same with a RUN-TIME chunk (work items per XCD group), for launches whose caller sets it
+__device__ __forceinline__ int xcd_block_rt(int b, int nblocks, int chunk) {
+    const int full = nblocks / (NXCD * chunk) * (NXCD * chunk);
+    if (b >= full) return b;
+    const int xcd = b % NXCD, pos = b / NXCD;
+    return ((pos / chunk) * NXCD + xcd) * chunk + pos % chunk;
+}
+
 // Every wave-per-ray kernel is launched as BS threads x ceil(n / (BS / 64)) workgroups, so the
 // grid and workgroup sizes follow from the kernel's own argument n: reading gridDim / blockDim
 // instead costs a wavefront that lives for ONE ray two more dependent fetches (the hidden
 // kernel arguments; blockDim even through the vector memory path) before its first row load:
 // k_depth -4 %, k_bp and k_sweep_map -1 % (profiles/r02_exp_wave_startup.txt).
 template <int BS = BLOCK, int CHUNK = 0>
-__device__ __forceinline__ int ray_of_wave(int n, int &lane) {
+__device__ __forceinline__ int ray_of_wave(int n, int &lane, int chunk_rt = 0) {
     constexpr int WPB = BS / WAVE;
     lane = threadIdx.x & (WAVE - 1);
 #ifdef RN_HIDDEN_ARG_DIMS
     const int b = xcd_block<CHUNK>(blockIdx.x, gridDim.x);
     const int r = uniform(b * (int)(blockDim.x >> 6) + (threadIdx.x >> 6));
 #else
-    const int b = xcd_block<CHUNK>(blockIdx.x, (n + WPB - 1) / WPB);
+    const int b = chunk_rt > 0 ? xcd_block_rt(blockIdx.x, (n + WPB - 1) / WPB, chunk_rt)
+                               : xcd_block<CHUNK>(blockIdx.x, (n + WPB - 1) / WPB);
     // the wave's ray index lives in an SGPR (the compiler cannot see that threadIdx.x >> 6 is
     // wave-uniform): row addresses become scalar base + per-lane 32-bit offset
     const int r = uniform(b * WPB + (int)(threadIdx.x >> 6));
@@ -278,11 +287,6 @@ struct rn_ctx {
     int prof_cap, prof_n;
     hipEvent_t *prof_ev;      // 2 * prof_cap
     int32_t *prof_id, *prof_rays;
-    // launches recorded into a HIP graph (rn_prof_graph_*): external event-record nodes
-    uint32_t gprof_mask;
-    int gprof_n;
-    hipEvent_t gprof_ev[2 * 64];
-    int32_t gprof_id[64], gprof_rays[64];
     char err[512];
 };
 
@@ -290,32 +294,17 @@ struct rn_ctx {
 struct ProfScope {
     rn_ctx *c;
     hipStream_t st;
-    int slot, gslot;
-    ProfScope(rn_ctx *ctx, int id, int n_rays, hipStream_t s) : c(ctx), st(s), slot(-1), gslot(-1) {
+    int slot;
+    ProfScope(rn_ctx *ctx, int id, int n_rays, hipStream_t s) : c(ctx), st(s), slot(-1) {
         if (c->prof_on && ((c->prof_mask >> id) & 1u) && c->prof_n < c->prof_cap) {
             slot = c->prof_n++;
             c->prof_id[slot] = id;
             c->prof_rays[slot] = n_rays;
             (void)hipEventRecord(c->prof_ev[2 * slot], st);
-        } else if (((c->gprof_mask >> id) & 1u) && c->gprof_n < 64) {
-            // a launch that is being CAPTURED: external event-record nodes travel with it
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
-                const int g = c->gprof_n;
-                if (!c->gprof_ev[2 * g] && (hipEventCreate(&c->gprof_ev[2 * g]) != hipSuccess ||
-                                            hipEventCreate(&c->gprof_ev[2 * g + 1]) != hipSuccess))
-                    return;
-                gslot = c->gprof_n++;
-                c->gprof_id[gslot] = id;
-                c->gprof_rays[gslot] = n_rays;
-                (void)hipEventRecordWithFlags(c->gprof_ev[2 * gslot], st, hipEventRecordExternal);
-            }
         }
     }
     ~ProfScope() {
         if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], st);
-        if (gslot >= 0)
-            (void)hipEventRecordWithFlags(c->gprof_ev[2 * gslot + 1], st, hipEventRecordExternal);
     }
 };
 
@@ -387,6 +376,7 @@ struct SweepArgs {
     float *msgs_out = nullptr;      // MAPMODE 3: BP iteration 0's messages
     float prior = 0.0f;             // MAPMODE 3: occupancy_to_ray(prior, 0), see first_occupancy()
     float *zero = nullptr;          // MAPMODE 3: cleared on the side (rn_acc_size floats)
+    int xcd_chunk = 0;              // workgroups per XCD group (0: RN_XCD_CHUNK_SWEEP)
 };
 
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
@@ -399,7 +389,7 @@ void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
                        ctx->axes, a.vox, a.rvc, a.S_planes, a.S_voxel, a.depth_from_planes,
                        a.points, a.order, a.fv_table, a.cam_stride, a.rows_per_image, a.seg,
                        a.msgs_out, a.prior, reinterpret_cast<float4 *>(a.zero),
-                       a.zero ? (int)(acc_floats(ctx) / 4) : 0);
+                       a.zero ? (int)(acc_floats(ctx) / 4) : 0, a.xcd_chunk);
 }
 
 // pick the plane-sweep flavour: cooperative for F=32 and 2..9 views, generic otherwise
@@ -793,8 +783,6 @@ void rn_destroy(rn_ctx *ctx) {
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->aux) hipStreamDestroy(ctx->aux);
-    for (int i = 0; i < 2 * 64; i++)
-        if (ctx->gprof_ev[i]) hipEventDestroy(ctx->gprof_ev[i]);
     for (int i = 0; i < 2 * ctx->prof_cap; i++) hipEventDestroy(ctx->prof_ev[i]);
     delete[] ctx->prof_ev;
     delete[] ctx->prof_id;
@@ -1213,7 +1201,8 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
                                   const int32_t *ray_idxs, const float *const *features_views,
                                   const float *cameras, const int32_t *order, int32_t *vox,
                                   int32_t *rvc, float *Sr, float *ray_segments, void *stream,
-                                  float *msgs_fold, float prior, float *zero_fold = nullptr) {
+                                  float *msgs_fold, float prior, float *zero_fold = nullptr,
+                                  int sweep_xcd_chunk = 0) {
     if (!ctx || n_images < 1 || n < 0 || rows_per_image < n || !ray_idxs || !features_views ||
         !cameras || !vox || !rvc || !Sr)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -1264,6 +1253,7 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
         a.rows_per_image = rows_per_image;
         a.n_images = ng;
         a.seg = ray_segments ? ray_segments + row0 * 8 : nullptr;
+        a.xcd_chunk = sweep_xcd_chunk / WAVES_PER_BLOCK;
         if (msgs_fold) {
             a.msgs_out = msgs_fold + row0 * M;
             a.prior = o_first;
@@ -1427,7 +1417,8 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
         (!(phases & RN_RUN_DEPTH_RANGE) && image >= pl->n_images) ||
         (!pl->ray_idxs && pl->n) || !pl->features_views || !pl->cameras || !pl->vox || !pl->rvc || !pl->Sr || !pl->msgs ||
         !pl->acc[0] || !pl->acc[1] || !pl->depth ||
-        (pl->depth_image && pl->depth_image_stride < 1) ||
+        (pl->depth_image && pl->depth_image_stride < 1) || pl->sweep_xcd_chunk < 0 ||
+        pl->sweep_xcd_chunk % 4 ||
         (phases & ~(RN_RUN_PREPARE | RN_RUN_SWEEP | RN_RUN_COMBINE | RN_RUN_DEPTH | RN_RUN_DEPTH_RANGE)) ||
         ((phases & RN_RUN_DEPTH_RANGE) &&
          (image < 0 || (image >> 16) < 1 || (image & 0xffff) + (image >> 16) > pl->n_images ||
@@ -1454,7 +1445,8 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
                                         pl->features_views, pl->cameras, pl->order, pl->vox,
                                         pl->rvc, pl->Sr, pl->ray_segments, stream,
                                         folded ? pl->msgs : nullptr, pl->prior,
-                                        folded && !fixed ? pl->acc[0] : nullptr);
+                                        folded && !fixed ? pl->acc[0] : nullptr,
+                                        pl->sweep_xcd_chunk);
         if (rc) return rc;
     }
     if (pl->n == 0) {
@@ -1563,34 +1555,6 @@ int rn_prof_end(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host, int32_t *
         if (n_rays_host) n_rays_host[i] = ctx->prof_rays[i];
     }
     *count = n;
-    return RN_OK;
-}
-
-int rn_prof_graph_begin(rn_ctx *ctx, uint32_t kernel_mask) {
-    if (!ctx) return RN_ERR_INVALID;
-    ctx->gprof_mask = kernel_mask;
-    ctx->gprof_n = 0;
-    return RN_OK;
-}
-
-int rn_prof_graph_end(rn_ctx *ctx) {
-    if (!ctx) return RN_ERR_INVALID;
-    ctx->gprof_mask = 0;
-    return RN_OK;
-}
-
-int rn_prof_graph_read(rn_ctx *ctx, int32_t *count, int32_t *kernel_ids_host,
-                       int32_t *n_rays_host, float *ms_host) {
-    if (!ctx || !count) return fail(ctx, RN_ERR_INVALID, "bad argument");
-    for (int i = 0; i < ctx->gprof_n; i++) {
-        float ms = 0.0f;
-        RN_HIP(ctx, hipEventSynchronize(ctx->gprof_ev[2 * i + 1]));
-        RN_HIP(ctx, hipEventElapsedTime(&ms, ctx->gprof_ev[2 * i], ctx->gprof_ev[2 * i + 1]));
-        if (ms_host) ms_host[i] = ms;
-        if (kernel_ids_host) kernel_ids_host[i] = ctx->gprof_id[i];
-        if (n_rays_host) n_rays_host[i] = ctx->gprof_rays[i];
-    }
-    *count = ctx->gprof_n;
     return RN_OK;
 }
 

@@ -369,7 +369,7 @@ void k_sweep_map(
     float *S_voxel, float *depth_from_planes, float *points,
     const int32_t *__restrict__ order, const float *const *__restrict__ fv_table, int cam_stride,
     int64_t rows_per_image, const float *__restrict__ seg, float *msgs_out, float o_first,
-    float4 *zero_buf, int zero_count4) {
+    float4 *zero_buf, int zero_count4, int xcd_chunk) {
     constexpr bool RESIDENT = MAPMODE >= 2;      // value-only divisions through the reciprocal
     // MAPMODE 3 stands in for the first k_bp launch of a pass, including what that launch clears
     // on the side: the partial accumulator the first scatter adds into (see k_bp)
@@ -407,7 +407,7 @@ void k_sweep_map(
         __syncthreads();
     }
     int lane;
-    int r = ray_of_wave<BLOCK, RN_XCD_CHUNK_SWEEP>(n, lane);
+    int r = ray_of_wave<BLOCK, RN_XCD_CHUNK_SWEEP>(n, lane, xcd_chunk);
     if (r < 0) return;
     RN_PHASE_DECL;
     RN_PHASE_MARK(0);                      // (clock read only)

@@ -342,7 +342,6 @@ class RayNetForwardPass(ForwardPass):
         self._pass_complete = True
         self.trace = None          # a list: eager passes bracket their exchanges with events (_mark)
         self.captured = False      # whether the last pass was a graph replay
-        self.graph_events = None   # kernel families whose captured launches carry event nodes
         self.ref_idx = -1
         self._ctx = None
         self._de = None
@@ -379,15 +378,6 @@ class RayNetForwardPass(ForwardPass):
     @accumulator.setter
     def accumulator(self, value):
         self._acc_grid, self._acc_flat, self._acc_bias = value, None, 0.0
-
-    def set_graph_events(self, families):
-        """Kernel families (HipContext.KERNEL_NAMES) whose launches are bracketed by external
-        event-record nodes INSIDE the captured step (rn_prof_graph_*): every replay re-records
-        them, `ctx.prof_graph_read()` after a completed pass returns that pass's durations.
-        Graphs captured before are dropped (the next passes capture again)."""
-        self.graph_events = list(families) if families else None
-        if self._plan is not None and "graphs" in self._plan:
-            self._plan["graphs"] = {}
 
     # -- helpers -----------------------------------------------------------
     def _context(self, scene, F):
@@ -473,6 +463,7 @@ class RayNetForwardPass(ForwardPass):
                         shared = tile_order(shared, H, W, *opt.ray_tile, along_rows=along_rows)
                 rays = shared
             lists[r] = rays
+        self._along_rows = along_rows
         return lists, shared
 
     def _plan_cuts(self, ctx, dist, refs, lists, shared, cam_dev, world):
@@ -650,6 +641,7 @@ class RayNetForwardPass(ForwardPass):
                     cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
                     balance=balance, shards=shards, npad=npad, shared=shared,
                     patch_rows=patch_rows, orders={}, stitch=None, fast=None, slot=0, direct=False,
+                    along_rows=self._along_rows,
                     table=torch.tensor(ptrs, dtype=torch.int64).to(dev) if V else None)
         self._plan_buffers(ctx, plan, refs, old_bytes)
         # static views of every image's rows in the scene-wide buffers
@@ -677,6 +669,18 @@ class RayNetForwardPass(ForwardPass):
                 order = row_major_order(shards[0][0], H, W) if shards[0][0].numel() else None
             elif "rows" in modes:
                 fast_ok = False           # per-image schedules: the launch-by-launch path
+        if fast_ok and patch_rows and opt.sweep_tile is not None and shards[0][0].numel():
+            # the plane sweep's own schedule over patch-ordered rows: which ray the i-th
+            # wavefront takes (results do not depend on it)
+            ridx = shards[0][0].to(torch.int64)
+            tx, ty = opt.sweep_tile
+            x, y = ridx // H, ridx % H
+            along = bool(plan["along_rows"])
+            if along:
+                key = (((y // ty) * ((W + tx - 1) // tx) + x // tx) * ty + y % ty) * tx + x % tx
+            else:
+                key = (((x // tx) * ((H + ty - 1) // ty) + y // ty) * tx + x % tx) * ty + y % ty
+            order = torch.argsort(key).to(torch.int32)
         if dist is not None and world > 1 and hasattr(ctx, "scene_run"):
             # the two paths exchange differently (per-image all-gathers / one): every rank must
             # take the same one, and a rank's HBM budget may have decided otherwise
@@ -694,7 +698,8 @@ class RayNetForwardPass(ForwardPass):
                 V, npad, shards[0][0], plan["table"], cam_dev, plan["vox"], plan["rvc"],
                 plan["Sr"], plan["msgs"], plan["acc_a"], plan["acc_b"], plan["depth"],
                 plan["prior"], patch_rows, acc_fixed=plan["acc_part"] if plan["fixed"] else None,
-                order=order, **({"depth_image": plan["maps_dev"]} if plan["direct"] else {}))
+                order=order, sweep_xcd_chunk=opt.sweep_xcd_chunk,
+                **({"depth_image": plan["maps_dev"]} if plan["direct"] else {}))
         if not self._filter_out_rays:
             self._plan = plan
         return plan
@@ -772,18 +777,26 @@ class RayNetForwardPass(ForwardPass):
             # into pixel order and writes the pinned host maps across PCIe itself.
             mine = [k for k in range(V) if owners[k] == rank]
             n_own = len(mine)
-            blk = n_own * npad                       # one source rank's rows of my images
+            # how the rows travel (PathOptions.rows_exchange): "all_to_all" sends a rank's rows of
+            # image k to k's owner only (blk = my images' rows of one source rank); "all_gather"
+            # (default) hands every rank everybody's rows and the owners pick theirs -- 5 MB more
+            # per rank and step on links that are idle at that point, and the one of the two
+            # RCCL captures into a HIP graph on this runtime (an all-to-all inside a capture
+            # takes the process down: tools/r04_rccl_probe.py)
+            a2a = self.options.rows_exchange == "all_to_all"
+            blk = n_own * npad if a2a else V * npad     # one source rank's block in `recv`
             recv = torch.zeros((world * blk + 1,), dtype=torch.float32, device=dev)
             table = None
             if n_own:
                 idx = torch.empty((n_own, HW), dtype=torch.int32, device=dev)
                 for j, k in enumerate(mine):
                     st = stitch_index(k, refs[k])
-                    at = (st // npad) * blk + j * npad + st % npad
+                    at = (st // npad) * blk + (j if a2a else k) * npad + st % npad
                     idx[j] = torch.where(st == world * npad, torch.full_like(at, world * blk),
                                          at).to(torch.int32)
                 table = idx.reshape(-1)
-            plan["a2a"] = dict(mine=mine, recv=recv, table=table, out_split=[blk] * world,
+            plan["a2a"] = dict(mine=mine, recv=recv, table=table, all_to_all=a2a,
+                               out_split=[blk] * world,
                                in_split=[npad * sum(1 for o in owners if o == d)
                                          for d in range(world)])
             return
@@ -944,7 +957,7 @@ class RayNetForwardPass(ForwardPass):
                 plan["ev_ready"][a].record()
             self._emit_direct(plan, groups, slot)
         elif dist is not None and plan.get("a2a") is not None:
-            # owner-only maps: ONE depth launch over all of this rank's rows, ONE all-to-all
+            # owner-only maps: ONE depth launch over all of this rank's rows, ONE collective
             # that takes image k's rows of every rank to k's owner, ONE stitch launch there
             a2a = plan["a2a"]
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, 0 | (V << 16))
@@ -953,8 +966,11 @@ class RayNetForwardPass(ForwardPass):
             with torch.cuda.stream(side):
                 side.wait_event(plan["ev_ready"][0])
                 self._mark("gather", True)
-                _all_to_all_rows(dist, a2a["recv"][:-1], plan["depth"], a2a["out_split"],
-                                 a2a["in_split"])
+                if a2a["all_to_all"]:
+                    _all_to_all_rows(dist, a2a["recv"][:-1], plan["depth"], a2a["out_split"],
+                                     a2a["in_split"])
+                else:
+                    dist.all_gather_into_tensor(a2a["recv"][:-1], plan["depth"])
                 self._mark("gather", False)
                 mine = a2a["mine"]
                 if mine:
@@ -1017,12 +1033,17 @@ class RayNetForwardPass(ForwardPass):
         collectives are stream work (RCCL; gloo runs on the host), the scatter's adaptive tile
         shape settled (its probe launches copy counters to the host, and the shape is baked into
         the graph), nobody bracketing launches with events."""
-        if not (self.options.capture and ctx.device.type == "cuda" and hasattr(ctx, "scatter_settled")):
+        mode = self.options.capture
+        if mode == "off" or (mode == "auto" and dist is None) or ctx.device.type != "cuda" or \
+                not hasattr(ctx, "scatter_settled"):
             return False
         if self.trace is not None or getattr(ctx, "prof_active", False):
             return False
         if dist is not None and not (getattr(dist, "capturable", False) or _backend_of(dist) == "nccl"):
             return False
+        if dist is not None and plan.get("a2a") is not None and plan["a2a"]["all_to_all"] and \
+                not getattr(dist, "capturable", False):
+            return False              # (RCCL's all-to-all inside a capture: see _epilogue_buffers)
         return plan["passes"] >= 2 and ctx.scatter_settled()
 
     # -- the resident schedule ------------------------------------------------------------------
@@ -1082,24 +1103,20 @@ class RayNetForwardPass(ForwardPass):
             plan["slot"] = slot
             # (a pass whose launches or exchanges are bracketed by events runs eagerly)
             eager = self.trace is not None or getattr(ctx, "prof_active", False) or \
-                not self.options.capture
+                self.options.capture == "off"
             graph = None if eager else plan["graphs"].get(slot)
             if graph is None and not eager and self._capturable(plan, ctx, dist):
                 # the whole step -- phases, exchanges, epilogue -- as ONE graph (per host set):
                 # no interpreter and no launch overhead between its launches from now on
                 try:
                     graph = torch.cuda.CUDAGraph()
-                    if self.graph_events and hasattr(ctx, "prof_graph_begin"):
-                        ctx.prof_graph_begin(self.graph_events)
                     with torch.cuda.graph(graph):
                         self._run_plan_path(plan, ctx, refs, dist, world, slot, captured=True)
-                    if self.graph_events and hasattr(ctx, "prof_graph_end"):
-                        ctx.prof_graph_end()
                     plan["graphs"][slot] = graph
                 except Exception as e:        # a transport / runtime that cannot be captured
                     import warnings
                     warnings.warn("raynet_amd: step capture failed (%s); eager schedule" % (e,))
-                    self.options = self.options.replace(capture=False)
+                    self.options = self.options.replace(capture="off")
                     plan["graphs"], graph = {}, None
                     torch.cuda.synchronize(dev)
             if graph is not None:

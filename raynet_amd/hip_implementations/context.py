@@ -322,26 +322,6 @@ class HipContext(object):
         return [(self.KERNEL_NAMES.get(ids[i], str(ids[i])), int(rays[i]), float(ms[i]))
                 for i in range(n.value)]
 
-    def prof_graph_begin(self, only):
-        """Launches of the named families CAPTURED from now on carry external event-record
-        nodes (rn_prof_graph_begin); prof_graph_end() stops that, prof_graph_read() returns the
-        last completed replay's (family, n_rays, ms) per captured launch."""
-        ids = {v: k for k, v in self.KERNEL_NAMES.items()}
-        mask = 0
-        for name in only:
-            mask |= 1 << ids[name]
-        self._check(self.lib.rn_prof_graph_begin(self._h, mask))
-
-    def prof_graph_end(self):
-        self._check(self.lib.rn_prof_graph_end(self._h))
-
-    def prof_graph_read(self):
-        ids, rays, ms = (ctypes.c_int32 * 64)(), (ctypes.c_int32 * 64)(), (ctypes.c_float * 64)()
-        n = ctypes.c_int32()
-        self._check(self.lib.rn_prof_graph_read(self._h, ctypes.byref(n), ids, rays, ms))
-        return [(self.KERNEL_NAMES.get(ids[i], str(ids[i])), int(rays[i]), float(ms[i]))
-                for i in range(n.value)]
-
     def selftest_arith(self, a, out):
         """out[2][n]: roundf(a), round_half_away(a) (tests only)."""
         self._check(self.lib.rn_selftest_arith(self._h, a.numel(), _ptr(a), _ptr(out), _stream()))
@@ -486,7 +466,7 @@ class HipContext(object):
 
     def scene_plan(self, n_images, rows_per_image, ray_idxs, feature_table, cameras, vox, rvc, Sr,
                    msgs, acc0, acc1, depth, prior, patch_rows, acc_fixed=None, order=None,
-                   depth_image=None):
+                   depth_image=None, sweep_xcd_chunk=0):
         """An rn_scene_plan over the caller's buffers, every tensor validated ONCE here; the
         returned object (which keeps them alive) goes to scene_run.  depth_image [n_images, R]:
         the depth sweeps write the maps in ray-index (pixel) order there instead of `depth`."""
@@ -516,6 +496,8 @@ class HipContext(object):
         pl.depth, pl.prior = depth.data_ptr(), float(prior)
         pl.row_layout = 1 if patch_rows else 0
         pl.depth_image, pl.depth_image_stride = None, 0
+        assert sweep_xcd_chunk >= 0 and sweep_xcd_chunk % 4 == 0
+        pl.sweep_xcd_chunk = int(sweep_xcd_chunk)
         if depth_image is not None:
             assert depth_image.dim() == 2 and depth_image.shape[0] == n_images
             _chk(depth_image, f32, depth_image.numel(), "depth_image")

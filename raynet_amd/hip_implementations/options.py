@@ -34,6 +34,11 @@ class PathOptions:
     ray_tile: Optional[Tuple[int, int]] = (16, 16)   # pixel patch per 256 rows; None: ray-index order
     tile_along: str = "auto"          # patches enumerated along image "rows" / "cols"; "auto": by the epipoles
     sweep_reorder: bool = True        # epipolar row-major schedule of the plane sweep for ray-index rows
+    sweep_tile: Optional[Tuple[int, int]] = None   # schedule of the plane sweep over patch-ordered rows:
+    #                                   consecutive wavefronts take the rays of (x, y)-pixel tiles of this
+    #                                   size instead of the rows as they lie (None); with sweep_xcd_chunk
+    #                                   rays (0: the library's 2048) side by side on one XCD
+    sweep_xcd_chunk: int = 0
     slab_boxes: bool = True           # the scatters merge the traversal's slab boxes instead of scanning
     plan_path: bool = True            # one C call per phase of a pass (rn_scene_run) when the pass qualifies
     depth_head: bool = True           # one GPU: all images but the last decoded by one launch
@@ -42,10 +47,13 @@ class PathOptions:
     #                                   stitch of a rank (the last group takes the rest); 0: the
     #                                   per-image exchange through index_select and a copy
     spin_wait: bool = False           # poll the maps' events instead of blocking on them
-    capture: bool = True              # the plan path's whole step (phases, exchanges, epilogue) as ONE
-    #                                   captured HIP graph per plan, replayed per pass: no interpreter and
-    #                                   no launch overhead between the launches (RCCL collectives are
-    #                                   captured with it; other transports keep the eager schedule)
+    capture: str = "auto"             # the plan path's whole step (phases, exchanges, epilogue) as ONE
+    #                                   captured HIP graph per plan, replayed per pass -- no interpreter and
+    #                                   no launch overhead between the launches: "on", "off", or "auto" =
+    #                                   with a process group only (one GPU gains nothing: the host runs
+    #                                   ahead of a 6.7 ms step anyway; a 1 ms step of eight ranks does not
+    #                                   wait for it: -5 %).  RCCL's collectives are captured with the
+    #                                   launches; other transports keep the eager schedule
     maps: str = "auto"                # what a pass yields: "view" = views of the plan's pinned host maps
     #                                   (valid until the second-next pass), "copy" = fresh arrays like the
     #                                   reference's .get() (forward_pass.py:739-744), "auto" = views until
@@ -63,6 +71,9 @@ class PathOptions:
     #                                   rank (k * world // images; the others yield None for it), "rank0",
     #                                   or "all" = every rank every map (all-gather + stitch + host copy
     #                                   on all of them: round 3's epilogue)
+    rows_exchange: str = "all_gather"  # how the depth rows reach the maps' owners: one all-gather (every
+    #                                   rank receives all rows, the owners use theirs; captured with the
+    #                                   step) or "all_to_all" (only what an owner needs travels; eager)
     exchange_pieces: int = 1          # a BP iteration's rows in this many image groups, each group's
     #                                   partial sums all-reduced on a side stream under the next group's
     #                                   kernels (K x the bytes on the wire)
@@ -78,16 +89,19 @@ class PathOptions:
         "RAYNET_RAY_TILE": ("ray_tile", _tile),
         "RAYNET_TILE_ALONG": ("tile_along", str),
         "RAYNET_SWEEP_REORDER": ("sweep_reorder", _flag),
+        "RAYNET_SWEEP_TILE": ("sweep_tile", _tile),
+        "RAYNET_SWEEP_XCD_CHUNK": ("sweep_xcd_chunk", int),
         "RAYNET_SLAB_BOXES": ("slab_boxes", _flag),
         "RAYNET_PLAN_PATH": ("plan_path", _flag),
         "RAYNET_DEPTH_HEAD": ("depth_head", _flag),
         "RAYNET_DIRECT_MAPS": ("direct_maps", _flag),
         "RAYNET_RANK_GROUP": ("rank_group", int),
         "RAYNET_SPIN_WAIT": ("spin_wait", _flag),
-        "RAYNET_CAPTURE": ("capture", _flag),
+        "RAYNET_CAPTURE": ("capture", lambda t: {"0": "off", "1": "on"}.get(str(t).strip(), str(t).strip())),
         "RAYNET_MAPS": ("maps", str),
         "RAYNET_GATHER": ("gather", str),
         "RAYNET_EXCHANGE_PIECES": ("exchange_pieces", int),
+        "RAYNET_ROWS_EXCHANGE": ("rows_exchange", str),
         "RAYNET_RESIDENT_GB": ("resident_gb", float),
         "RAYNET_DETERMINISTIC": ("deterministic", _flag),
         "RAYNET_SHARD": ("shard", str),
@@ -103,6 +117,9 @@ class PathOptions:
     def __post_init__(self):
         if self.ray_tile is not None:
             self.ray_tile = (int(self.ray_tile[0]), int(self.ray_tile[1]))
+        if self.sweep_tile is not None:
+            self.sweep_tile = (int(self.sweep_tile[0]), int(self.sweep_tile[1]))
+        assert self.sweep_xcd_chunk >= 0 and self.sweep_xcd_chunk % 4 == 0
         assert self.tile_along in ("auto", "rows", "cols"), self.tile_along
         assert self.shard in ("voxels", "rays"), self.shard
         assert self.exchange in ("allreduce", "reduce_scatter"), self.exchange
@@ -110,8 +127,10 @@ class PathOptions:
         assert self.overlap in (0, 1, 2)
         assert self.rank_group >= 0
         assert self.maps in ("auto", "copy", "view"), self.maps
+        assert self.capture in ("auto", "on", "off"), self.capture
         assert self.gather in ("owner", "rank0", "all"), self.gather
         assert self.exchange_pieces >= 1
+        assert self.rows_exchange in ("all_gather", "all_to_all"), self.rows_exchange
 
     @classmethod
     def from_env(cls, environ=None, **overrides):
@@ -132,6 +151,7 @@ class PathOptions:
     def as_dict(self):
         d = asdict(self)
         d["ray_tile"] = "%dx%d" % self.ray_tile if self.ray_tile else None
+        d["sweep_tile"] = "%dx%d" % self.sweep_tile if self.sweep_tile else None
         return d
 
     def context_options(self):
