@@ -69,8 +69,26 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-VALU_CLOCK_HZ = 2.4e9     # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, a wave64 VALU instruction = 4 cycles
+VALU_CLOCK_HZ = 2.4e9     # nominal shader clock; 256 CUs x 4 SIMDs
 N_SIMDS = 1024
+MEASURED_COPY_GBS = 6290.0    # MI355X_MICROARCH.md: measured device-to-device copy rate
+
+
+def valu_cycles_per_inst(family, config):
+    """Cycles one SIMD needs to issue one wave64 VALU instruction of this kernel: the MEASURED cost
+    of each instruction class (tools/valu_issue_bench.hip: plain fp32 / integer add, mul, fma,
+    logic ~2.3 - 2.9; packed, DPP, min / max / med3, shifts, conversions, compares, 24-bit mad ~4.1;
+    transcendentals ~8.1) weighted with the kernel's static instruction histogram
+    (tools/valu_mix.py -> profiles/valu_issue.json).  -> (cycles, source)"""
+    path = os.path.join(REPO, "profiles", "valu_issue.json")
+    try:
+        table = json.load(open(path))["kernels"]
+        for key in ("%s/%s" % (family, config), family + "/steady", family + "/box128x32", family):
+            if key in table:
+                return float(table[key]["mean_cycles"]), "profiles/valu_issue.json [%s]" % key
+    except Exception:
+        pass
+    return 4.0, "default (no profiles/valu_issue.json entry)"
 
 
 def algorithmic_bytes(kernel, n_rays, voxels, cfg, images=1, folded=False, strict=False):
@@ -89,11 +107,20 @@ def algorithmic_bytes(kernel, n_rays, voxels, cfg, images=1, folded=False, stric
         return images * 4 * N * F * Hf * Wf + (12 if folded else 8) * voxels + 40 * n_rays
     if kernel == "bp":            # Sr, voxel list, msg in, acc gather, msg out
         return 20 * voxels + 4 * n_rays
-    if kernel == "scatter":       # msg, voxel list, atomic RMW of the accumulator (8)
-        return 16 * voxels + 4 * n_rays
+    if kernel == "scatter":       # msg, voxel list (the HBM-side streams); the atomic RMW of the
+        # accumulator (8 B per visit in SURVEY.md 8(d)'s count) never leaves LDS / L2 -- the LDS box
+        # sums ~11 visits per voxel, the 8.4 MB accumulator lives in the L2 -- and is reported
+        # on its own (cache_resident_bytes), not as HBM traffic
+        return 8 * voxels + 4 * n_rays
     if kernel == "depth":         # Sr, voxel list, msg, acc gather; depth out
         return 16 * voxels + 8 * n_rays
     return 0
+
+
+def cache_resident_bytes(kernel, voxels):
+    """Bytes of SURVEY.md 8(d)'s per-visit model that stay in LDS / L2 by construction (not HBM
+    traffic): the scatter's read-modify-write of the accumulator, 8 B per visit."""
+    return 8 * voxels if kernel == "scatter" else 0
 
 
 KERNEL_OF_FAMILY = {"sweep_map": "k_sweep_map", "bp": "k_bp", "scatter": "k_scatter_box",
@@ -362,7 +389,7 @@ def main():
     def account(recorded):
         fam = {}
         for name, n_rays, ms in recorded:
-            f = fam.setdefault(name, dict(ms=0.0, launches=0, bytes=0.0, strict=0.0))
+            f = fam.setdefault(name, dict(ms=0.0, launches=0, bytes=0.0, strict=0.0, resident=0.0))
             f["ms"] += ms
             f["launches"] += 1
             if n_rays:
@@ -374,6 +401,7 @@ def main():
                 f["bytes"] += algorithmic_bytes(name, n_rays, vox, cfg_acc, images=images, folded=folded)
                 f["strict"] += algorithmic_bytes(name, n_rays, vox, cfg_acc, images=images,
                                                  folded=folded, strict=True)
+                f["resident"] += cache_resident_bytes(name, vox)
         return fam
 
     fam = account(launches_all)             # the breakdown steps: every family
@@ -416,15 +444,23 @@ def main():
         # what binds the kernel: the time its algorithmic bytes need at the HBM peak, or the time
         # its VALU instructions need to ISSUE (4 cycles each on one of 1024 SIMDs) -- counters
         # from the same separate PMC passes as `traffic`
-        valu_issue_ms = valu_insts * 4.0 / (N_SIMDS * VALU_CLOCK_HZ) * 1e3 if valu_insts else None
+        cyc, cyc_source = valu_cycles_per_inst(dominant, args.config)
+        valu_issue_ms = valu_insts * cyc / (N_SIMDS * VALU_CLOCK_HZ) * 1e3 if valu_insts else None
         strict = d["strict"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
-        roofline = dict(bound="valu" if (valu_issue_ms or 0.0) > hbm_ms else "hbm", kernel=dominant,
+        # what binds: the larger of (a) the time the kernel's memory-side bytes need -- the
+        # algorithmic ones at the HBM peak, or what the counters saw leave the L2 (FETCH / WRITE:
+        # HBM and Infinity Cache alike) at the measured copy rate -- and (b) its VALU-issue time
+        traffic_ms = traffic / (MEASURED_COPY_GBS * 1e9) * 1e3 if traffic else None
+        mem_ms = max(hbm_ms, traffic_ms or 0.0)
+        roofline = dict(bound="valu" if (valu_issue_ms or 0.0) > mem_ms else "hbm", kernel=dominant,
                         achieved=round(achieved, 1),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                         traffic=traffic, traffic_source=traffic_source,
                         avg_launch_ms=round(avg_ms, 4), launches=d["launches"],
                         algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
                         hbm_time_ms=round(hbm_ms, 4),
+                        l2_side_traffic_time_ms=round(traffic_ms, 4) if traffic_ms else None,
+                        valu_cycles_per_inst=cyc, valu_cycles_source=cyc_source,
                         valu_insts_per_launch=valu_insts,
                         valu_issue_ms=round(valu_issue_ms, 4) if valu_issue_ms else None,
                         valu_frac=round(valu_issue_ms / avg_ms, 4) if valu_issue_ms else None,
@@ -443,7 +479,11 @@ def main():
                        timeline_share_ms_per_step=round(by_family.get(k, 0.0) / breakdown_steps, 3),
                        launches_per_step=v["launches"] / breakdown_steps,
                        algorithmic_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
-                       if v["ms"] > 0 and v["bytes"] else None)
+                       if v["ms"] > 0 and v["bytes"] else None,
+                       **({"cache_resident_GBps": round(v["resident"] / (v["ms"] * 1e-3) / 1e9, 1),
+                           "cache_resident_what": "accumulator read-modify-write of SURVEY.md 8(d)'s "
+                                                  "count (8 B per visit): LDS box + L2, not HBM"}
+                          if v["resident"] and v["ms"] > 0 else {}))
                for k, v in sorted(fam.items())}
 
     # ---- CPU baseline, two legs on bounded ray samples drawn from ALL reference images -------

@@ -434,7 +434,16 @@ inline int box_split(int n, int tile_rays) {
 #ifndef RN_BOX_SPLIT_MAX
 #define RN_BOX_SPLIT_MAX 4
 #endif
-    return max(1, min(RN_BOX_SPLIT_MAX, RN_BOX_SPLIT_TARGET / max(tiles, 1)));
+    // (RAYNET_HIP_BOX_SPLIT="target,max": A/B override, read once)
+    static int target = 0, most = 0;
+    if (!target) {
+        target = RN_BOX_SPLIT_TARGET;
+        most = RN_BOX_SPLIT_MAX;
+        if (const char *e = getenv("RAYNET_HIP_BOX_SPLIT")) (void)sscanf(e, "%d,%d", &target, &most);
+        if (target < 1) target = 1;
+        if (most < 1) most = 1;
+    }
+    return max(1, min(most, target / max(tiles, 1)));
 }
 
 // One BP sweep: k_bp (messages) + the accumulator scatter that fits the row layout.
