@@ -32,8 +32,43 @@ class SimpleCNN(nn.Module):
         self.net = nn.Sequential(*layers)
         self.filters = filters
 
+    # Below this spatial size and above this batch an input is a batch of PATCHES (config 5: the
+    # 11 x 11 patches around the rays' projected sample points, 32,000 per view and call,
+    # tf_implementations/forward_backward_pass.py:177-182) and takes the row-matrix path.
+    PATCH_MAX_SIDE, PATCH_MIN_BATCH = 16, 2048
+
     def forward(self, x):           # NCHW
+        if x.dim() == 4 and max(x.shape[-2:]) <= self.PATCH_MAX_SIDE and \
+                x.shape[0] >= self.PATCH_MIN_BATCH and min(x.shape[-2:]) >= 3:
+            return self.forward_patches(x)
         return self.net(x)
+
+    def forward_patches(self, x):
+        """The same five [Conv 3x3 valid, BatchNorm(, ReLU)] blocks for a large batch of small
+        patches, as row matrices: every layer is ONE GEMM  [B * h' * w', 9 C] x [9 C, 32]  on the
+        im2col rows (channels-last, so a 3 x 3 x C window is a contiguous-inner gather), batch
+        normalisation over the rows (= BatchNorm2d's statistics over (N, h, w)), ReLU.  MIOpen's
+        convolution solvers for 32,000 images of 11 x 11 take 160 ms per view forward + backward
+        (profiles/r03_train_bench_config5.txt); five skinny GEMMs and their unfold copies take a
+        fraction of that.  Same arithmetic as `self.net` up to the summation order of a dot
+        product of 9 C terms (tests/test_models.py).  NCHW in, NCHW out."""
+        from torch.nn import functional as F
+        y = x.permute(0, 2, 3, 1)                                  # [B, h, w, C] (a view)
+        for i, (conv, bn) in enumerate(self._blocks()):
+            B, h, w, C = y.shape
+            # [B, h-2, w-2, C, 3, 3] windows -> rows [B (h-2) (w-2), 3 * 3 * C] in (ky, kx, c) order
+            cols = y.unfold(1, 3, 1).unfold(2, 3, 1).permute(0, 1, 2, 4, 5, 3)
+            rows = cols.reshape(B * (h - 2) * (w - 2), 9 * C)
+            wm = conv.weight.permute(2, 3, 1, 0).reshape(9 * C, conv.out_channels)
+            out = torch.addmm(conv.bias, rows, wm)
+            if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            out = F.batch_norm(out, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                               bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
+            if i < 4:
+                out = F.relu(out)
+            y = out.view(B, h - 2, w - 2, conv.out_channels)
+        return y.permute(0, 3, 1, 2)
 
     # ---- weights in the reference's (Keras) order and layouts -----------------------
     def _blocks(self):

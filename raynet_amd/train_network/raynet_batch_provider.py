@@ -28,9 +28,23 @@ def project_points(P, points):
     return q[..., :2] / q[..., 2:3]
 
 
+def patches_inside(image_hw, P, points, patch_shape=(11, 11)):
+    """common/image.py:175-193: [n] bool -- every one of the ray's D patches lies inside the image
+    (`min_x >= 0, min_y >= 0, max_x <= w, max_y <= h`).  The reference's `Image.patches` returns
+    None for a sample with ANY patch outside, and the batch provider draws another ray
+    (raynet_batch_provider.py:81: `if sample.X is not None`)."""
+    h, w = patch_shape
+    H, W = image_hw
+    centre = torch.round(project_points(P, points)).long()
+    min_x, max_x = centre[..., 0] - w // 2, centre[..., 0] + w // 2 + w % 2
+    min_y, max_y = centre[..., 1] - h // 2, centre[..., 1] + h // 2 + h % 2
+    return ((min_x >= 0) & (min_y >= 0) & (max_x <= W) & (max_y <= H)).all(dim=1)
+
+
 def patches_from_3d_points(image_chw, P, points, patch_shape=(11, 11)):
     """common/image.py:145-200 for every point of every ray: [n, D, C, h, w].  Patches that
-    reach over the image border are zero there (the reference's `expand_patch` padding)."""
+    reach over the image border are zero there -- such rays are not part of a reference batch
+    at all (patches_inside; get_batch_of_rays drops them by default)."""
     h, w = patch_shape
     C, H, W = image_chw.shape
     pad = max(h, w)
@@ -58,11 +72,18 @@ def one_hot_target(voxel_of_point, ray_voxel_indices, ray_voxel_count):
 
 
 def get_batch_of_rays(scene, ref_idx, ray_idxs, generation_params, hip, images, target_points,
-                      patch_shape=(11, 11)):
-    """The reference's `inputs` list for `n = len(ray_idxs)` rays of reference image `ref_idx`.
+                      patch_shape=(11, 11), reject_border_rays=True, return_valid=False):
+    """The reference's `inputs` list for the rays of `ray_idxs` of reference image `ref_idx`.
 
     hip: HipContext of the scene (M, D, H, W, bbox, grid); images: {view: [C, H, W] CUDA
-    tensor}; target_points [n, 3]: the ground-truth surface point of every ray."""
+    tensor}; target_points [n, 3]: the ground-truth surface point of every ray.
+    reject_border_rays (default, the reference's rule): a ray ANY of whose D x N patches reaches
+    over an image border is not in the batch (common/image.py:189-193 returns None, the provider
+    redraws); the batch then holds the `valid` rays only, in order -- draw more candidates than
+    the batch needs.  return_valid: also return the [len(ray_idxs)] bool mask.
+    Layout notes: images_v is channels-first [n, D, C, h, w] (Keras: [n, D, h, w, C]); voxel_grid
+    is [gx][gy][gz][3] (the layout forward_pass.py:573-575 hands the kernels; the training
+    provider's `voxel_grid` input is the reference's [3][gx][gy][gz] -- transpose(3, 0, 1, 2))."""
     gp = generation_params
     views = scene.view_indices_with_neighbors(ref_idx, gp.neighbors)
     cam = scene.get_image(ref_idx).camera
@@ -77,9 +98,11 @@ def get_batch_of_rays(scene, ref_idx, ray_idxs, generation_params, hip, images, 
     rvc = torch.zeros((n,), dtype=torch.int32, device=dev)
     hip.voxel_traversal(points[:, 0, :3].contiguous(), points[:, -1, :3].contiguous(), rvi, rvc)   # K5
     patches = []
+    valid = torch.ones((n,), dtype=torch.bool, device=dev)
     for v in views:
         P = torch.as_tensor(np.asarray(scene.get_image(v).camera.P, np.float32), device=dev)
         patches.append(patches_from_3d_points(images[v], P, points, patch_shape))
+        valid &= patches_inside(images[v].shape[1:], P, points, patch_shape)
     bbox = torch.as_tensor(np.asarray(scene.bbox, np.float32).ravel(), device=dev)
     grid = torch.as_tensor(np.asarray(hip.grid_shape, np.float32), device=dev)
     voxel = torch.floor((torch.as_tensor(target_points, dtype=torch.float32, device=dev) - bbox[:3]) /
@@ -87,4 +110,8 @@ def get_batch_of_rays(scene, ref_idx, ray_idxs, generation_params, hip, images, 
     S_target = one_hot_target(voxel, rvi, rvc)
     voxel_grid = hip.dev(np.ascontiguousarray(scene.voxel_grid(gp.grid_shape).transpose(1, 2, 3, 0)))
     centers = center[None, :].expand(n, 4).contiguous()
-    return patches + [voxel_grid, rvi, rvc, S_target, points, centers]
+    if reject_border_rays:
+        patches = [p[valid] for p in patches]
+        rvi, rvc, S_target, points, centers = (t[valid] for t in (rvi, rvc, S_target, points, centers))
+    out = patches + [voxel_grid, rvi, rvc, S_target, points, centers]
+    return (out, valid) if return_valid else out

@@ -88,12 +88,23 @@ def test_training_step_on_restrepo_cameras_with_the_mvcnn_twin(oracle_mod):
     X = (c[:, None] + t * d).T
     inside = (t > 0) & np.all(X > bbox[:3] + 0.05, 1) & np.all(X < bbox[3:] - 0.05, 1)
     assert inside.sum() >= 1000, inside.sum()
-    ray_idxs, target_points = cand[inside][:1000], X[inside][:1000]
-    n = len(ray_idxs)
-
     images_dev = {v: torch.from_numpy(images[v]).permute(2, 0, 1).contiguous().cuda()
                   for v in range(VIEWS)}
-    batch = get_batch_of_rays(scene, ref, ray_idxs, gp, hip, images_dev, target_points)
+    # candidates -> the reference's rule: a ray ANY of whose D x N patches reaches over an image
+    # border is redrawn (common/image.py:189-193, raynet_batch_provider.py:81); the first 1000
+    # that pass are the batch
+    cand_rays, cand_points, t_cand = cand[inside], X[inside], t[inside]
+    batch, valid = get_batch_of_rays(scene, ref, cand_rays, gp, hip, images_dev, cand_points,
+                                     return_valid=True)
+    valid = valid.cpu().numpy()
+    assert valid.sum() >= 1000 and (~valid).sum() > 0, (valid.sum(), len(valid))
+    keep_all = get_batch_of_rays(scene, ref, cand_rays[:64], gp, hip, images_dev, cand_points[:64],
+                                 reject_border_rays=False)
+    assert len(keep_all[VIEWS + 1]) == 64
+    ray_idxs, target_points, t_rays = cand_rays[valid][:1000], cand_points[valid][:1000], \
+        t_cand[valid][:1000]
+    n = len(ray_idxs)
+    batch = [b if i == VIEWS else b[:n] for i, b in enumerate(batch)]     # (the voxel grid is no row list)
     patches, (voxel_grid, rvi, rvc, S_target, points, centers) = batch[:VIEWS], batch[VIEWS:]
     assert len(patches) == VIEWS and tuple(patches[0].shape) == (n, D, 3, 11, 11)
     assert tuple(points.shape) == (n, D, 4) and tuple(rvi.shape) == (n, M, 3)
@@ -121,7 +132,7 @@ def test_training_step_on_restrepo_cameras_with_the_mvcnn_twin(oracle_mod):
     assert np.mean(np.all(tv == np.floor((target_points - bbox[:3]) / bins), 1)) > 0.97
     #  * at the hypothesis nearest the surface every view sees the same texture (what the
     #    similarity has to find): patch centres agree across views there, not elsewhere
-    dist = np.abs(along - t[inside][:1000, None])
+    dist = np.abs(along - t_rays[:, None])
     near = dist.argmin(1)
     ctr = np.stack([p[np.arange(n), near, :, 5, 5].cpu().numpy() for p in patches])     # [V, n, 3]
     far = np.stack([p[np.arange(n), (near + D // 2) % D, :, 5, 5].cpu().numpy() for p in patches])

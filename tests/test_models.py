@@ -87,3 +87,48 @@ def test_forward_pass_script_takes_reference_ordered_weights(tmp_path):
     x = rng.random((1, 26, 28, 3)).astype(np.float32)
     want = numpy_forward(x, weights)
     assert np.abs(net.predict(x).cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_patch_batches_take_the_row_matrix_path_with_the_same_results():
+    """Config 5 feeds the twin 32,000 patches of 11 x 11 per view and call
+    (tf_implementations/forward_backward_pass.py:177-182).  `SimpleCNN.forward` sends such a
+    batch through `forward_patches` -- per layer one GEMM on im2col rows + batch normalisation
+    over the rows -- instead of MIOpen's small-image convolutions: the same function (float64:
+    to rounding, values and every gradient; float32: to the dot products' summation order),
+    the same running statistics, train and eval mode."""
+    import copy
+    import torch
+    from raynet_amd.models import SimpleCNN
+    torch.manual_seed(0)
+    m = SimpleCNN().double().train()
+    m2 = copy.deepcopy(m)
+    x = torch.randn(SimpleCNN.PATCH_MIN_BATCH, 3, 11, 11, dtype=torch.float64, requires_grad=True)
+    t = torch.randn(len(x), 32, 1, 1, dtype=torch.float64)
+    y1 = m.net(x)
+    g1 = torch.autograd.grad(((y1 - t) ** 2).sum(), [x] + list(m.parameters()))
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = m2(x2)                       # dispatches on the shape
+    assert y2.shape == y1.shape == (len(x), 32, 1, 1)
+    g2 = torch.autograd.grad(((y2 - t) ** 2).sum(), [x2] + list(m2.parameters()))
+    assert float((y1 - y2).abs().max()) < 1e-12
+    for a, b in zip(g1, g2):
+        assert float((a - b).abs().max()) <= 1e-11 * max(1.0, float(a.abs().max()))
+    for b1, b2 in zip(m.net, m2.net):
+        if isinstance(b1, torch.nn.BatchNorm2d):
+            assert torch.allclose(b1.running_mean, b2.running_mean, atol=1e-14)
+            assert torch.allclose(b1.running_var, b2.running_var, atol=1e-14)
+            assert int(b1.num_batches_tracked) == int(b2.num_batches_tracked) == 1
+    m.eval()
+    m2.eval()
+    assert float((m.net(x) - m2(x)).abs().max()) < 1e-12
+    # a whole image (or a small batch) keeps the convolution path
+    calls = []
+    m2.forward_patches = lambda z: calls.append(1)
+    m2(torch.randn(2, 3, 40, 40, dtype=torch.float64))
+    m2(torch.randn(8, 3, 11, 11, dtype=torch.float64))
+    assert not calls
+    # float32: the dot products' summation order only
+    f = SimpleCNN().train()
+    xf = torch.randn(SimpleCNN.PATCH_MIN_BATCH, 3, 11, 11)
+    f2 = copy.deepcopy(f)
+    assert float((f.net(xf) - f2(xf)).abs().max()) < 1e-4

@@ -100,11 +100,14 @@ def config5(n=1000, D=32, M=160, grid=(64, 64, 32), steps=10, H=90, W=160, views
               for v in range(views)}
     rng = np.random.default_rng(3)
     # pixels of the image interior (their rays cross the box); the target point is synthetic
-    px, py = rng.integers(20, W - 20, n), rng.integers(15, H - 15, n)
+    # (3 n candidates: rays with a patch over an image border are redrawn, as the reference does)
+    px, py = rng.integers(20, W - 20, 3 * n), rng.integers(15, H - 15, 3 * n)
     ray_idxs = (px * H + py).astype(np.int32)
-    targets = rng.uniform(bbox[:3] + 0.5, bbox[3:] - 0.5, (n, 3))
+    targets = rng.uniform(bbox[:3] + 0.5, bbox[3:] - 0.5, (3 * n, 3))
     t0 = time.perf_counter()
     batch = get_batch_of_rays(scene, 2, ray_idxs, gp, hip, images, targets)
+    batch = [b_ if i == views else b_[:n] for i, b_ in enumerate(batch)]
+    assert len(batch[views + 1]) == n, "too few candidates survive the border rule"
     torch.cuda.synchronize()
     t_batch = time.perf_counter() - t0
     patches, (vg_d, rvi, rvc, target, points, cams) = batch[:views], batch[views:]
