@@ -922,6 +922,58 @@ class RayNetForwardPass(ForwardPass):
             self._mark("exchange", False)
         ctx.scene_run(fast, _lib.RN_RUN_COMBINE, it)
 
+    def _pieces(self, plan, ctx, V):
+        """PathOptions.exchange_pieces = K > 1: the images in K contiguous groups, each with its
+        own partial accumulator and a copy of the C plan whose SWEEP phase covers the group's
+        rows and scatters into that partial (HipContext.scene_plan_piece)."""
+        K = min(int(self.options.exchange_pieces), V)
+        if K <= 1 or plan["fast"] is None or not hasattr(ctx, "scene_plan_piece"):
+            return None
+        if "pieces" not in plan:
+            G, dev, fixed = ctx.acc_size(), ctx.device, plan["fixed"]
+            cuts = [V * p // K for p in range(K + 1)]
+            parts = torch.zeros((K, G), dtype=torch.float32, device=dev)
+            parts_fixed = torch.zeros((K, G), dtype=torch.int64, device=dev) if fixed else None
+            structs = [[ctx.scene_plan_piece(plan["fast"], cuts[p], cuts[p + 1] - cuts[p], parts[p], e,
+                                             parts_fixed[p] if fixed else None) for e in (0, 1)]
+                       for p in range(K)]
+            plan["pieces"] = dict(K=K, parts=parts, parts_fixed=parts_fixed, structs=structs,
+                                  ev=[torch.cuda.Event() for _ in range(K)]
+                                  if dev.type == "cuda" else None)
+            if self._side_stream is None and dev.type == "cuda":
+                self._side_stream, self._copy_stream = _side_streams(dev)
+        return plan["pieces"]
+
+    def _sweep_in_pieces(self, plan, ctx, dist, pc, it):
+        """BP iteration `it` (>= 1) group by group: a group's k_bp + scatter into ITS partial, then
+        the all-reduce of that partial on the side stream -- under the next group's kernels; the
+        accumulator is the sum of the K reduced partials (the prior is added where it is read,
+        once, as ever).  What it buys and what it costs: DESIGN.md section 8 -- K all-reduces of
+        the FULL accumulator size instead of one, of which the last is exposed as before."""
+        K, fixed = pc["K"], plan["fixed"]
+        out = plan["acc_b" if it & 1 else "acc_a"]
+        bufs = pc["parts_fixed"] if fixed else pc["parts"]
+        side = self._side_stream
+        for p in range(K):
+            ctx.scene_run(pc["structs"][p][it & 1], _lib.RN_RUN_SWEEP, it)
+            if dist is None:
+                continue
+            pc["ev"][p].record()
+            with torch.cuda.stream(side):
+                side.wait_event(pc["ev"][p])
+                self._mark("exchange", True)
+                dist.all_reduce(bufs[p], op=dist.ReduceOp.SUM)
+                self._mark("exchange", False)
+        if dist is not None:
+            torch.cuda.current_stream(ctx.device).wait_stream(side)
+        if fixed:
+            # integer sums: the same bits as one scatter into one partial, whatever K
+            torch.sum(bufs, dim=0, out=plan["acc_part"])
+            bufs.zero_()
+            ctx.scene_run(plan["fast"], _lib.RN_RUN_COMBINE, it)
+        else:
+            torch.sum(bufs, dim=0, out=out)
+
     def _run_plan_path(self, plan, ctx, refs, dist, world, slot, captured=False):
         """One pass as phases of the C plan (include/raynet_hip.h, rn_scene_run): 1 + T calls
         for the K1 prefix and the T BP iterations, the exchange between them, then the depth
@@ -937,7 +989,11 @@ class RayNetForwardPass(ForwardPass):
                 plan["acc_b"].fill_(plan["prior"])
             else:
                 plan["acc_b"].zero_()
+        pieces = self._pieces(plan, ctx, len(refs)) if T > 1 else None
         for it in range(T):
+            if pieces is not None and it > 0:
+                self._sweep_in_pieces(plan, ctx, dist, pieces, it)
+                continue
             ctx.scene_run(fast, (_lib.RN_RUN_PREPARE if it == 0 else 0) | _lib.RN_RUN_SWEEP, it)
             self._exchange(plan, ctx, dist, world, it)
         final = plan["acc_b" if (T - 1) & 1 else "acc_a"]
@@ -1241,22 +1297,37 @@ class RayNetForwardPass(ForwardPass):
             # shipped quirk every iteration does (memmap reopened with mode="w+", Q1)
             first = it == 0 or self.reference_quirks
             plan["dirty"] = True
+            # PathOptions.exchange_pieces = K > 1 (a process group, all columns resident): the
+            # images in K groups, each scattering into its own partial, which is all-reduced as
+            # soon as the group is done; the accumulator is the sum of the reduced partials
+            K = min(int(self.options.exchange_pieces), V) if (collective and one_group and groups) else 1
+            if K > 1 and "granular_parts" not in plan:
+                plan["granular_parts"] = [torch.zeros_like(acc_part) for _ in range(K)]
             for group in groups:
                 if not one_group:
                     prepare(group)
                 n_g = len(group) * npad
                 g_row0 = group[0] * npad
                 B_g = self.rays_batch // 256 * 256 if self.rays_batch and self.rays_batch >= 256 else n_g
-                for i in range(0, n_g, B_g):
-                    sweep(Sr_g[i:min(i + B_g, n_g)], vox_g[i:min(i + B_g, n_g)],
-                          rvc_all[g_row0 + i:g_row0 + min(i + B_g, n_g)], acc_in,
-                          msgs_all[g_row0 + i:g_row0 + min(i + B_g, n_g)], acc_part,
-                          first_sweep=first, patch_rows=patch_rows,
-                          uniform_acc=it == 0)      # iteration 0: the prior everywhere
+                cuts = [V * p // K * npad for p in range(K + 1)] if K > 1 else [0, n_g]
+                for p in range(len(cuts) - 1):
+                    part = plan["granular_parts"][p] if K > 1 else acc_part
+                    for i in range(cuts[p], cuts[p + 1], B_g):
+                        j = min(i + B_g, cuts[p + 1])
+                        sweep(Sr_g[i:j], vox_g[i:j], rvc_all[g_row0 + i:g_row0 + j], acc_in,
+                              msgs_all[g_row0 + i:g_row0 + j], part,
+                              first_sweep=first, patch_rows=patch_rows,
+                              uniform_acc=it == 0)      # iteration 0: the prior everywhere
+                    if K > 1:
+                        dist.all_reduce(part, op=dist.ReduceOp.SUM)
             # swap + prior refill of forward_pass.py:676-678; across ranks the partial sums are
             # merged first (integer sums in the deterministic mode: the same bits whatever the
             # ring order) and the prior is added once, after the sum
-            if collective:
+            if K > 1:
+                torch.sum(torch.stack(plan["granular_parts"]), dim=0, out=acc_part)
+                for part in plan["granular_parts"]:
+                    part.zero_()
+            elif collective:
                 dist.all_reduce(acc_part, op=dist.ReduceOp.SUM)
             combine(acc_part, prior, acc_next)
             # (the prior buffer never becomes a destination)

@@ -510,6 +510,34 @@ class HipContext(object):
         pl._ref = ctypes.byref(pl)
         return pl
 
+    def scene_plan_piece(self, plan, first_image, n_images, acc_out, parity, acc_fixed=None):
+        """A copy of `plan` restricted to the images [first_image, first_image + n_images) whose
+        SWEEP phase of an iteration with `iteration & 1 == parity` scatters into `acc_out`
+        (rn_acc_size floats) instead of the plan's own accumulator -- and reads the plan's other
+        accumulator as it is (PathOptions.exchange_pieces).  acc_fixed: the piece's own int64
+        partial in the deterministic mode."""
+        pl = _lib.ScenePlan()
+        ctypes.pointer(pl)[0] = plan          # field-by-field copy of the struct
+        M, rows0 = self.M, int(first_image) * int(plan.rows_per_image)
+        cam_stride = 12 * self.N + 16
+        assert 0 <= first_image and n_images >= 1 and first_image + n_images <= plan.n_images
+        _chk(acc_out, torch.float32, self.acc_size(), "acc_out", align=16)
+        _chk(acc_fixed, torch.int64, self.acc_size(), "acc_fixed", optional=True, align=16)
+        pl.n_images = int(n_images)
+        pl.features_views = plan.features_views + 8 * first_image * self.N
+        pl.cameras = plan.cameras + 4 * first_image * cam_stride
+        pl.vox, pl.Sr, pl.msgs = (getattr(plan, f) + 4 * rows0 * M for f in ("vox", "Sr", "msgs"))
+        pl.rvc, pl.depth = plan.rvc + 4 * rows0, plan.depth + 4 * rows0
+        if plan.ray_segments:
+            pl.ray_segments = plan.ray_segments + 4 * rows0 * 8
+        pl.depth_image = None
+        pl.acc[parity] = acc_out.data_ptr()
+        pl.acc[1 - parity] = plan.acc[1 - parity]
+        pl.acc_fixed = acc_fixed.data_ptr() if acc_fixed is not None else None
+        pl._keepalive = (plan, acc_out, acc_fixed)
+        pl._ref = ctypes.byref(pl)
+        return pl
+
     def scene_run(self, plan, phases, iteration=0, image=-1):
         """rn_scene_run: the phases (a mask of _lib.RN_RUN_*) of one pass, one C call."""
         self._check(self.lib.rn_scene_run(self._h, plan._ref, int(phases), int(iteration),

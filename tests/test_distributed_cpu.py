@@ -20,7 +20,7 @@ from conftest import REPO
 H, W, D, M, GRID, VIEWS = 12, 16, 8, 48, (16, 16, 16), 3
 
 
-def _run(rank, world, port, out_dir, filtered=False, gather="owner"):
+def _run(rank, world, port, out_dir, filtered=False, gather="owner", pieces=1):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from host_backend import OracleBackend
@@ -45,7 +45,8 @@ def _run(rank, world, port, out_dir, filtered=False, gather="owner"):
     fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 50,
                                             filter_out_rays=filtered,
                                             backend_factory=OracleBackend,
-                                            options=PathOptions.from_env(gather=gather))
+                                            options=PathOptions.from_env(gather=gather,
+                                                                         exchange_pieces=pieces))
     depths = list(fp.forward_pass(scene, (0, VIEWS, 1)))
     # with a process group image k's map is handed out by ONE rank (PathOptions.gather, the
     # reference needs it once: forward_pass.py:739-744); the others yield None for it
@@ -56,7 +57,7 @@ def _run(rank, world, port, out_dir, filtered=False, gather="owner"):
         for d, m in zip(depths, masks):
             assert d is None or ((d[m == 0] == 0).all() and (d[m != 0] > 0).all())
     depths = [d if d is not None else np.zeros((H, W), np.float32) for d in depths]
-    tag = "f" if filtered else ""
+    tag = ("f" if filtered else "") + ("p%d" % pieces if pieces > 1 else "")
     rows = np.array([len(fp.ray_index[r]) for r in range(VIEWS)])
     np.savez(os.path.join(out_dir, "%sw%d_r%d.npz" % (tag, world, rank)), depth=np.stack(depths),
              owned=owned,
@@ -132,3 +133,20 @@ def test_two_rank_filtered_rays_and_patch_rows(tmp_path):
     assert np.array_equal(r0["acc"], r1["acc"])
     assert np.abs(one["acc"] - r0["acc"]).max() < 1e-4
     assert (np.abs(one["depth"] - _merged([r0, r1], "owner")) > 1e-4).mean() < 0.01
+
+
+@pytest.mark.timeout(300)
+def test_exchange_in_pieces_equals_one_exchange(tmp_path):
+    """PathOptions.exchange_pieces = K: a BP iteration's images in K groups, every group's partial
+    sums all-reduced on their own (on hardware: on a side stream, under the next group's kernels)
+    and added up afterwards -- the accumulator and the maps of the one-exchange schedule (float
+    sums in another order: the usual tolerance; the real kernels' fixed-point mode: the same
+    bits, tests/test_forward_pass_gpu.py)."""
+    out = str(tmp_path)
+    mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_run, args=(2, _free_port(), out, False, "owner", 3), nprocs=2, join=True)
+    one = [np.load(os.path.join(out, "w2_r%d.npz" % q)) for q in range(2)]
+    pcs = [np.load(os.path.join(out, "p3w2_r%d.npz" % q)) for q in range(2)]
+    assert np.array_equal(pcs[0]["acc"], pcs[1]["acc"])
+    assert np.abs(one[0]["acc"] - pcs[0]["acc"]).max() < 1e-4
+    assert (np.abs(_merged(one, "owner") - _merged(pcs, "owner")) > 1e-4).mean() < 0.01

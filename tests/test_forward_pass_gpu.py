@@ -273,7 +273,8 @@ def _rank_main(rank, world, port, out_dir, deterministic=False, gather="all"):
                                             options=PathOptions.from_env(
                                                 gather=gather.split("+")[0],
                                                 rows_exchange="all_to_all" if "+a2a" in gather
-                                                else "all_gather"))
+                                                else "all_gather",
+                                                exchange_pieces=3 if "+pieces" in gather else 1))
     gather = gather.split("+")[0]
     depths = list(fp.forward_pass(scene, (0, 5, 1)))
     if world > 1 and gather != "all":
@@ -302,7 +303,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,gather", [(2, "owner"), (4, "owner+a2a"), (8, "owner"), (8, "all"),
-                                          (8, "owner+a2a"), (4, "rank0"), (2, "all")])
+                                          (8, "owner+a2a"), (4, "rank0"), (2, "all"),
+                                          (4, "owner+pieces")])
 def test_sharded_ranks_on_real_kernels(torch, tmp_path, world, gather):
     """2 / 4 / 8 ranks (gloo, all on cuda:0 -- RCCL needs one GPU per rank) run the real HIP
     kernels on their voxel-balanced ray shards; the merged accumulator and depth maps equal
@@ -441,6 +443,37 @@ def test_captured_step_replays_the_eager_pass(torch):
         for i in range(len(seen)):
             d = np.stack([m.copy() for m in auto.forward_pass(scene, (0, 5, 1))])
         assert not auto.captured and np.array_equal(d, first)
+
+
+def test_exchange_pieces_change_no_bit_in_fixed_point(torch):
+    """PathOptions.exchange_pieces = K: iterations >= 1 run group by group (K image groups, each
+    k_bp + scatter into its own partial accumulator, the partials summed afterwards -- with a
+    process group each is all-reduced under the next group's kernels).  Integer sums are
+    associative: in the fixed-point mode accumulator, messages and maps are the K = 1 bits for
+    every K; in float mode they agree to the usual re-association tolerance."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.hip_implementations.options import PathOptions
+    from raynet_amd.synthetic import make_synthetic_scene
+    H, W = 48, 64
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
+    gp = _gp(32, 192, (64, 64, 64))
+    cls = get_forward_pass_factory("raynet")
+    res = {}
+    for det in (True, False):
+        for K in (1, 2, 3, 5, 9):
+            fp = cls(bank, gp, "sample_in_bbox", (H, W), 0,
+                     options=PathOptions(deterministic=det, exchange_pieces=K))
+            d = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+            assert ("pieces" in fp._plan) == (K > 1)
+            if K > 1:
+                assert fp._plan["pieces"]["K"] == min(K, 5)
+            res[det, K] = (d, fp.accumulator.cpu().numpy(), fp.messages[3].cpu().numpy())
+    for K in (2, 3, 5, 9):
+        for a, b in zip(res[True, 1], res[True, K]):
+            assert np.array_equal(a, b), K
+        assert np.abs(res[False, 1][1] - res[False, K][1]).max() <= 5e-4
+        assert np.abs(res[False, 1][2] - res[False, K][2]).max() <= 1e-4
+        assert (np.abs(res[False, 1][0] - res[False, K][0]) > 1e-4).mean() < 0.01
 
 
 def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
@@ -682,6 +715,7 @@ def _nccl_single_main(port, out_dir):
                      ("all", PathOptions(deterministic=True, gather="all", capture="off")),
                      ("a2a", PathOptions(deterministic=True, rows_exchange="all_to_all")),
                      ("cap", PathOptions(deterministic=True)),
+                     ("cappc", PathOptions(deterministic=True, exchange_pieces=2)),
                      ("capall", PathOptions(deterministic=True, gather="all")),
                      ("g", PathOptions(plan_path=False))):
         fp = get_forward_pass_factory("raynet")(bank, _gp(32, 192, (64, 64, 64)), "sample_in_bbox",
@@ -708,7 +742,8 @@ def _nccl_single_main(port, out_dir):
              acc_rs=res["rs"][1], depth_granular=res["g"][0], acc_granular=res["g"][1],
              depth_all=res["all"][0], acc_all=res["all"][1], depth_a2a=res["a2a"][0],
              acc_a2a=res["a2a"][1], depth_cap=res["cap"][0],
-             acc_cap=res["cap"][1], depth_capall=res["capall"][0], acc_capall=res["capall"][1])
+             acc_cap=res["cap"][1], depth_capall=res["capall"][0], acc_capall=res["capall"][1],
+             depth_cappc=res["cappc"][0], acc_cappc=res["cappc"][1])
     dist.destroy_process_group()
 
 
@@ -739,7 +774,7 @@ def test_rccl_code_path_in_a_one_rank_world(torch, tmp_path):
     assert np.array_equal(got["depth_fixed"], ref_d["depth"])
     assert np.array_equal(got["acc_rs"], ref_d["acc"])             # ... whatever the exchange
     assert np.array_equal(got["depth_rs"], ref_d["depth"])
-    for tag in ("all", "a2a", "cap", "capall"):                    # ... the epilogue, eager or captured
+    for tag in ("all", "a2a", "cap", "capall", "cappc"):           # ... the epilogue / the pieces, eager or captured
         assert np.array_equal(got["acc_" + tag], ref_d["acc"]), tag
         assert np.array_equal(got["depth_" + tag], ref_d["depth"]), tag
     assert np.abs(got["acc_granular"] - ref["acc"]).max() < 5e-4
