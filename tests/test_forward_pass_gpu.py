@@ -642,14 +642,25 @@ def test_ranks_without_rays_take_part_in_the_exchange(torch, monkeypatch):
             monkeypatch.setattr(F, "_dist", lambda s=stub, r=rank: (s, r, world))
             fp = F.get_forward_pass_factory("raynet")(
                 bank, _gp(8, 48, (16, 16, 16), neighbors=2), "sample_in_bbox", (H, W), 0,
-                options=PathOptions(shard="rays", deterministic=det))
+                options=PathOptions(shard="rays", deterministic=det, gather="all"))
             maps = list(fp.forward_pass(scene, (0, 3, 1)))
             assert fp._plan["fast"] is not None
             assert len(maps) == 3 and maps[0].shape == (H, W) and np.isfinite(np.stack(maps)).all()
+            calls = list(stub.calls)
+            if det:     # owner-only maps (the default): image k from rank k * world // images only
+                monkeypatch.setattr(F, "_dist", lambda s=Stub(world), r=rank: (s, r, world))
+                own = F.get_forward_pass_factory("raynet")(
+                    bank, _gp(8, 48, (16, 16, 16), neighbors=2), "sample_in_bbox", (H, W), 0,
+                    options=PathOptions(shard="rays", deterministic=det))
+                got = list(own.forward_pass(scene, (0, 3, 1)))
+                for k in range(3):
+                    assert (got[k] is not None) == (F.map_owner(k, 3, world, "owner") == rank)
+                    if got[k] is not None:
+                        assert np.array_equal(got[k], maps[k])
             n = len(fp.ray_index[0])
             empty += n == 0
             # three exchanges of the sums (+ the agreement on the path), one all-gather per image
-            assert stub.calls.count("all_gather") == 3 and stub.calls.count("all_reduce") >= 3
+            assert calls.count("all_gather") == 3 and calls.count("all_reduce") >= 3
             if n == 0:
                 # nothing of an earlier pass survives in a rank's partial sums: all zero
                 acc = fp._acc_flat if not det else None
@@ -779,6 +790,30 @@ def test_rccl_code_path_in_a_one_rank_world(torch, tmp_path):
         assert np.array_equal(got["depth_" + tag], ref_d["depth"]), tag
     assert np.abs(got["acc_granular"] - ref["acc"]).max() < 5e-4
     assert (np.abs(got["depth_granular"] - ref["depth"]) > 1e-4).mean() < 0.01
+
+
+def test_step_records_give_the_scatter_the_same_lists(torch, tmp_path, monkeypatch):
+    """RAYNET_HIP_STEP_LISTS=1 (experiment): k_traverse also leaves the lists
+    as step records -- first voxel + 2-bit axis codes, 0.5 bytes per step -- and the box scatter
+    decodes those instead of reading the 4-byte words.  The same lists, so in the fixed-point
+    mode the same accumulator and maps, bit for bit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    runs = {}
+    for tag, env in (("plain", None), ("steps", "1")):
+        out = tmp_path / tag
+        out.mkdir()
+        if env is None:
+            monkeypatch.delenv("RAYNET_HIP_STEP_LISTS", raising=False)
+        else:
+            monkeypatch.setenv("RAYNET_HIP_STEP_LISTS", env)
+        p = ctx.Process(target=_rank_main, args=(0, 1, 0, str(out), True))
+        p.start()
+        p.join(300)
+        assert p.exitcode == 0
+        runs[tag] = np.load(str(out / "dw1_r0.npz"))
+    assert np.array_equal(runs["plain"]["acc"], runs["steps"]["acc"])
+    assert np.array_equal(runs["plain"]["depth"], runs["steps"]["depth"])
 
 
 def test_resident_schedule_in_memory_bounded_groups(torch, monkeypatch):
