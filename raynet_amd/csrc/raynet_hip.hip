@@ -278,8 +278,6 @@ struct rn_ctx {
     const int32_t *sb_vox;
     int64_t sb_rows, sb_valid_lo, sb_valid_hi;
     int2 *sb_boxes;
-    int2 *sb_steps;       // step records of the bound list buffer (RAYNET_HIP_STEP_LISTS=1), or null
-    int step_lists;
     int overlap;          // 0 off, 1 on, 2 (default) when the scatter runs at tile level >= 1
     hipStream_t aux;
     hipEvent_t ev_fork, ev_join;
@@ -427,12 +425,6 @@ inline int2 *slab_boxes_for(const rn_ctx *ctx, const int32_t *vox, int64_t n, bo
     return ctx->sb_boxes + (row0 / WAVE) * slab_box_count(ctx->p.M);
 }
 
-// ... and its step records (raynet_kernels.h: decode_step), when the experiment is on
-inline int2 *step_recs_for(const rn_ctx *ctx, const int32_t *vox, int64_t n, bool need_valid) {
-    if (!ctx->sb_steps || !slab_boxes_for(ctx, vox, n, need_valid)) return nullptr;
-    return ctx->sb_steps + ((vox - ctx->sb_vox) / ctx->p.M) * (ctx->p.M / STEP_REC);
-}
-
 // workgroups per box-scatter tile (grid.y): enough of them for ~16 per CU
 inline int box_split(int n, int tile_rays) {
     const int tiles = (n + tile_rays - 1) / tile_rays;
@@ -499,15 +491,12 @@ void launch_scatter_kernel(rn_ctx *ctx, int n, const float *msgs, const int32_t 
                            const int32_t *rvc, void *acc_out, hipStream_t st, int level,
                            bool fixed) {
     ProfScope prof(ctx, RN_K_SCATTER, n, st);
-    const int2 *recs = PACKED ? step_recs_for(ctx, vox, n, true) : nullptr;
-#define RN_BOX_(RAYS, STEPS, FIXED_, CAP, SL_)                                                    \
-    hipLaunchKernelGGL((k_scatter_box<PACKED, RAYS, STEPS, FIXED_, SL_>),                         \
+#define RN_BOX(RAYS, STEPS, FIXED_, CAP)                                                          \
+    hipLaunchKernelGGL((k_scatter_box<PACKED, RAYS, STEPS, FIXED_>),                              \
                        dim3((n + RAYS - 1) / RAYS, box_split(n, RAYS)), dim3(BLOCK),              \
                        (CAP) * sizeof(double), st, ctx->p, n, msgs, vox, rvc, acc_out,            \
                        ctx->box_stats, CAP,                                                       \
-                       (const int2 *)(PACKED ? slab_boxes_for(ctx, vox, n, true) : nullptr), recs)
-#define RN_BOX(RAYS, STEPS, FIXED_, CAP)                                                          \
-    do { if (PACKED && recs) RN_BOX_(RAYS, STEPS, FIXED_, CAP, PACKED); else RN_BOX_(RAYS, STEPS, FIXED_, CAP, false); } while (0)
+                       (const int2 *)(PACKED ? slab_boxes_for(ctx, vox, n, true) : nullptr))
 #ifndef RN_BOX0_CAP
 #define RN_BOX0_CAP 4096
 #endif
@@ -526,7 +515,6 @@ void launch_scatter_kernel(rn_ctx *ctx, int n, const float *msgs, const int32_t 
                            static_cast<float *>(acc_out));
     }
 #undef RN_BOX
-#undef RN_BOX_
 }
 
 template <bool PACKED, bool CLIP_IN>
@@ -769,7 +757,6 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     const char *ov = getenv("RAYNET_HIP_OVERLAP");
     ctx->overlap = ov ? (atoi(ov) != 0 ? 1 : 0) : 2;
     ctx->generic_sweep = getenv("RAYNET_HIP_GENERIC_SWEEP") != nullptr;
-    ctx->step_lists = getenv("RAYNET_HIP_STEP_LISTS") != nullptr && cfg->M % STEP_REC == 0;
     ctx->prof_mask = ~0u;
     if (sweep_lds(p) > 160 * 1024) {      // before anything is allocated
         delete ctx;
@@ -1092,13 +1079,8 @@ int rn_scatter_settled(const rn_ctx *ctx) {
     return ctx && ctx->box_probe == 0 ? 1 : 0;
 }
 
-static int64_t slab_box_ints(const rn_ctx *ctx, int64_t rows) {
-    return ((rows + WAVE - 1) / WAVE) * slab_box_count(ctx->p.M) * 2;
-}
 int64_t rn_slab_boxes_size(const rn_ctx *ctx, int64_t rows) {
-    if (!ctx || rows < 0) return 0;
-    // (+ the step records behind the boxes when RAYNET_HIP_STEP_LISTS is set: 2 ints per 16 steps)
-    return slab_box_ints(ctx, rows) + (ctx->step_lists ? rows * (ctx->p.M / STEP_REC) * 2 : 0);
+    return ctx && rows >= 0 ? ((rows + WAVE - 1) / WAVE) * slab_box_count(ctx->p.M) * 2 : 0;
 }
 
 int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int32_t *boxes) {
@@ -1106,8 +1088,6 @@ int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int3
     ctx->sb_vox = boxes ? vox : nullptr;
     ctx->sb_rows = boxes ? rows : 0;
     ctx->sb_boxes = reinterpret_cast<int2 *>(boxes);
-    ctx->sb_steps = boxes && ctx->step_lists
-                        ? reinterpret_cast<int2 *>(boxes + slab_box_ints(ctx, rows)) : nullptr;
     ctx->sb_valid_lo = ctx->sb_valid_hi = 0;
     return RN_OK;
 }
@@ -1258,7 +1238,6 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
             ctx->sb_valid_lo = ctx->sb_valid_hi = 0;
         }
     }
-    int2 *recs0 = boxes ? step_recs_for(ctx, vox, (int64_t)n_images * rows_per_image, false) : nullptr;
     // traverse + sweep of images [g0, g0 + ng); the traversal on `trav_st`, the sweep on `st`
     auto traverse = [&](int g0, int ng, hipStream_t trav_st) {
         const float *cam = cameras + (size_t)g0 * cam_stride;
@@ -1269,8 +1248,7 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
                            (const float *)nullptr, (const float *)nullptr, vox + row0 * M,
                            rvc + row0, cam_stride, rows_per_image,
                            ray_segments ? ray_segments + row0 * 8 : nullptr,
-                           boxes ? boxes + (row0 / WAVE) * slab_box_count(ctx->p.M) : nullptr,
-                           recs0 ? recs0 + row0 * (ctx->p.M / STEP_REC) : nullptr);
+                           boxes ? boxes + (row0 / WAVE) * slab_box_count(ctx->p.M) : nullptr);
     };
     auto sweep = [&](int g0, int ng, hipStream_t st) {
         const float *cam = cameras + (size_t)g0 * cam_stride;

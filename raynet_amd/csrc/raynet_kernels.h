@@ -629,30 +629,6 @@ __host__ __device__ __forceinline__ int slab_box_count(int M) {
     return (M + SLAB_BOX_STEPS - 1) / SLAB_BOX_STEPS;
 }
 
-// Step records (experiment, RAYNET_HIP_STEP_LISTS=1): the voxel list again, at 0.5 bytes per step
-// instead of 4 -- per ray and per 16 steps one int2 {base, codes}: base = the packed voxel of the
-// record's first step (bits 30 / 31: the ray steps DOWN along x / y), codes = sixteen 2-bit
-// fields, field i (i >= 1) = the axis of the move INTO step i (0 x, 1 y, 2 z); field 0 has no
-// move to describe and holds the z direction in its low bit.  A DDA moves one cell along one axis
-// per step (ray_tracing.pyx:166-197), so step j of the record is
-//   base + sx * #{i <= j : x} * 2^20 + sy * #{i <= j : y} * 2^10 + sz * #{i <= j : z},
-// three population counts.  k_traverse derives the codes from the words it flushes anyway,
-// decode_step gives the word back (bit-equal lists: the accumulators of a pass are the same bits
-// in the fixed-point mode with either list, tests/test_forward_pass_gpu.py).
-constexpr int STEP_REC = 16;
-__device__ __forceinline__ int decode_step(int2 rec, int j) {
-    const unsigned c = (unsigned)rec.y;
-    const unsigned lt = ((4u << (2 * j)) - 1u) & ~3u;          // fields 1 .. j
-    const int ny = __popc(c & 0x55555555u & lt), nz = __popc((c >> 1) & 0x55555555u & lt);
-    const int nx = j - ny - nz;
-    const unsigned b = (unsigned)rec.x;
-    int w = (int)(b & 0x3fffffffu);
-    w += ((b >> 30) & 1u ? -nx : nx) << 20;
-    w += ((b >> 31) ? -ny : ny) << 10;
-    w += (c & 1u) ? -nz : nz;
-    return w;
-}
-
 // ------------------------------------------------------------------- a4
 // planes_voxels_mapping.cu:6-92 for one ray, wave-parallel.
 //   * t_i is computed per lane;

@@ -593,15 +593,14 @@ struct AccSum<true> {
     }
 };
 
-template <bool PACKED, int BOX_RAYS, int BOX_STEPS, bool FIXED = false, bool STEP_LIST = false>
+template <bool PACKED, int BOX_RAYS, int BOX_STEPS, bool FIXED = false>
 __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                                        const float *__restrict__ msgs,
                                                        const int32_t *__restrict__ vox,
                                                        const int32_t *__restrict__ rvc,
                                                        void *acc_out_raw,
                                                        unsigned *overflow_stats, int BOX_CAP,
-                                                       const int2 *__restrict__ slab_boxes,
-                                                       const int2 *__restrict__ step_recs) {
+                                                       const int2 *__restrict__ slab_boxes) {
     typedef AccSum<FIXED> Sum;
     typename Sum::acc_t *acc_out = static_cast<typename Sum::acc_t *>(acc_out_raw);
     constexpr int BOX_NB = BOX_RAYS * BOX_STEPS / BLOCK;     // pairs per thread and chunk
@@ -695,10 +694,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             // rows of padding / short rays are read at the tile's first row: valid memory
             const int rr = ok ? r0 + j0 + k * STRIDE : r0, ss = ok ? st : 0;
             m[k] = msgs[(size_t)rr * p.M + ss];
-            if (STEP_LIST)      // 8 bytes per 16 steps (one request per 16 lanes) instead of 4 per step
-                v[k] = decode_step(step_recs[(size_t)rr * (p.M / STEP_REC) + ss / STEP_REC], ss % STEP_REC);
-            else
-                v[k] = load_packed<PACKED>(vox + (size_t)rr * p.M * (PACKED ? 1 : 3), ss);
+            v[k] = load_packed<PACKED>(vox + (size_t)rr * p.M * (PACKED ? 1 : 3), ss);
         }
     };
     auto process = [&](int s0, const float (&m)[BOX_NB], const int (&v)[BOX_NB], unsigned okmask) {

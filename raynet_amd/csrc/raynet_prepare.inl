@@ -57,8 +57,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                                                    const float *__restrict__ ends, int32_t *vox,
                                                    int32_t *rvc, int cam_stride,
                                                    int64_t rows_per_image, float *seg_out,
-                                                   int2 *slab_boxes = nullptr,
-                                                   int2 *step_recs = nullptr) {
+                                                   int2 *slab_boxes = nullptr) {
     static_assert(TRAV_TILE == SLAB_BOX_STEPS || !PACKED, "slab boxes are per flushed tile");
     __shared__ int32_t tile[WAVE * (TRAV_TILE + 1)];
     const int lane = threadIdx.x;
@@ -71,7 +70,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
         rvc += (size_t)g * rows_per_image;
         if (seg_out) seg_out += (size_t)g * rows_per_image * 8;
         if (slab_boxes) slab_boxes += (size_t)g * (rows_per_image / WAVE) * slab_box_count(p.M);
-        if (step_recs) step_recs += (size_t)g * rows_per_image * (p.M / STEP_REC);
     }
     if (slab_boxes) slab_boxes += (size_t)blockIdx.x * slab_box_count(p.M);
     const int r = r0 + lane;
@@ -211,33 +209,10 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
             // four steps per lane and store (16-byte aligned: M and the tile base are multiples
             // of 4): 4 store rounds per tile instead of 16; a row's last, partial group of four
             // is written entry by entry -- nothing beyond a ray's count is touched
-            // this thread's ray: does it step down along x / y / z (decode_step's signs)
-            const int my_signs = (step[0] < 0 ? 1 : 0) | (step[1] < 0 ? 2 : 0) | (step[2] < 0 ? 4 : 0);
 #pragma unroll
             for (int j = 0; j < WAVE; j += WAVE / 4) {
                 const int row = j + (lane >> 2), q4 = (lane & 3) * 4;
                 const int nv = min(__shfl(count, row) - base - q4, 4);
-                const int row_signs = __shfl(my_signs, row);
-                if (step_recs && r0 + row < n && __shfl(count, row) > base) {
-                    // the record of (row, this tile): four lanes a row, four 2-bit codes each --
-                    // the axis of the move INTO every step after the tile's first
-                    const int32_t *tw = tile + row * (TRAV_TILE + 1);
-                    unsigned byte = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int st = q4 + i;
-                        if (st >= 1 && i < nv) {
-                            const int d = abs(tw[st] - tw[st - 1]);
-                            byte |= (d >= (1 << 20) ? 0u : d >= (1 << 10) ? 1u : 2u) << (2 * i);
-                        }
-                    }
-                    int2 *rec = step_recs + (size_t)(r0 + row) * (p.M / STEP_REC) + base / STEP_REC;
-                    if (q4 == 0) {
-                        byte |= (unsigned)(row_signs >> 2) & 1u;             // z direction in field 0
-                        rec->x = tw[0] | ((row_signs & 1) << 30) | ((row_signs & 2) << 30);
-                    }
-                    reinterpret_cast<unsigned char *>(&rec->y)[lane & 3] = (unsigned char)byte;
-                }
                 if (r0 + row < n && nv > 0) {
                     const int32_t *t = tile + row * (TRAV_TILE + 1) + q4;
                     int32_t *dst = vox + (size_t)(r0 + row) * p.M + base + q4;
