@@ -303,8 +303,9 @@ def main():
     # (a dozen scatter launches after the plan was built): the remaining untimed passes until
     # then -- the same number on every rank, the criterion counts launches
     extra_warmup = 0
-    while fp.options.capture != "off" and (world > 1 or fp.options.capture == "on") and \
-            not fp.captured and extra_warmup < 8:
+    capturable = fp.options.capture == "on" or (world > 1 and backend == "nccl" and
+                                                  fp.options.capture == "auto")
+    while capturable and not fp.captured and extra_warmup < 8:
         step()
         extra_warmup += 1
     # Which family dominates: by its SHARE of the timeline, not by the sum of its launches'
@@ -536,10 +537,37 @@ def main():
             if tc >= 0.5 * target or n >= H * W:
                 break
             n = int(min(H * W, n * min(8.0, max(2.0, target / max(tc, 1e-6)))))
+        # why the many-thread rate is what it is: the same leg on ONE thread (a smaller sample),
+        # and what the box really grants this process (affinity mask, cgroup CPU quota)
+        o1 = oracle.Oracle(M=cfg["M"], D=cfg["D"], N=gp.neighbors + 1, F=cfg["F"], H=H, W=W,
+                           padding=cfg["padding"], bbox=scene.bbox.ravel(), grid_shape=cfg["grid"],
+                           threads=1)
+        o_all, o = o, o1
+        n1 = min(400, H * W)
+        t1, _ = cpu_run(n1)
+        o = o_all
+        one_thread = V * n1 / t1
+        try:
+            quota = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = "cgroup cpu.max %s" % ("unlimited" if quota[0] == "max" else
+                                            "%.1f CPUs" % (float(quota[0]) / float(quota[1])))
+        except Exception:
+            quota = "cgroup quota unknown"
+        try:
+            affinity = len(os.sched_getaffinity(0))
+        except Exception:
+            affinity = None
         port = dict(value=round(V * n / tc, 1), unit="rays/s", cores=threads, kind="port",
+                    one_thread_rays_per_s=round(one_thread, 1),
+                    speedup_over_one_thread=round(V * n / tc / one_thread, 2),
                     sample="%d rays of each of the %d reference images (of %d per step), 3 BP "
                            "sweeps + depth sweep with the oracle's fused K1/K2 "
-                           "(oracle/raynet_oracle.c, OpenMP), %.1f s" % (n, V, rays_per_step, tc))
+                           "(oracle/raynet_oracle.c, OpenMP over rays, `omp atomic` adds into ONE shared "
+                           "accumulator), %.1f s; one thread does %.0f rays/s, %d threads %.1f x that "
+                           "(affinity mask %s CPUs, %s): the threads this process may START are not the "
+                           "cores it GETS, and the shared accumulator's lines bounce between them"
+                           % (n, V, rays_per_step, tc, one_thread, threads, V * n / tc / one_thread,
+                              affinity, quota))
 
         def numpy_run(n_np):
             _, kept = cpu_run(n_np, keep=True)
