@@ -237,6 +237,17 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
 int64_t rn_slab_boxes_size(const rn_ctx *ctx, int64_t rows);
 int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int32_t *boxes);
 
+/* Work list of the LDS-box scatter for the rows [0, rows) of the list buffer `vox` at tile level
+ * `level` (0: 128 rays x 32 steps, 1: 256 x 16): items[i] = tile << 12 | first chunk << 6 | chunks
+ * -- one workgroup per item, in the list's order (the caller sorts longest first and never lists
+ * a chunk no ray of its tile reaches; every (tile, chunk) below the tile's longest ray must be in
+ * exactly one item).  A scatter launch over exactly these rows at that level takes the list;
+ * any other launch -- and every launch after items == NULL -- deals tiles x chunks out itself.
+ * The list depends on the rays' voxel counts only (ray_tracing.pyx:64-199), not on messages: it
+ * is built once per scene and shard.  Speed only: the sums are the same. */
+int rn_scene_bind_scatter_items(rn_ctx *ctx, const int32_t *vox, int64_t rows, int32_t level,
+                                const int32_t *items, int32_t count);
+
 /* What the adaptive accumulator scatter of the resident path last saw (diagnostics): the tile
  * shape in use (0: 128 rays x 32 steps, 1: 256 x 16, 2: slab scatter) and, of the launches
  * between the launcher's last two looks at the counters that have arrived on the host (they are

@@ -126,6 +126,7 @@ SIGNATURES = {
     "rn_scatter_reset": [_P],
     "rn_slab_boxes_size": [_P, _L],
     "rn_scene_bind_slab_boxes": [_P, _P, _L, _P],
+    "rn_scene_bind_scatter_items": [_P, _P, _L, _I, _P, _I],
     "rn_scatter_state": [_P, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_uint32),
                          ctypes.POINTER(ctypes.c_uint32)],
     "rn_scatter_settled": [_P],

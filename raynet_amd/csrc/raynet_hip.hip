@@ -278,6 +278,11 @@ struct rn_ctx {
     const int32_t *sb_vox;
     int64_t sb_rows, sb_valid_lo, sb_valid_hi;
     int2 *sb_boxes;
+    // work list of the box scatter (rn_scene_bind_scatter_items): the row range and tile level it
+    // was built for
+    const int32_t *sc_vox, *sc_items;
+    int64_t sc_rows;
+    int sc_level, sc_count;
     int overlap;          // 0 off, 1 on, 2 (default) when the scatter runs at tile level >= 1
     hipStream_t aux;
     hipEvent_t ev_fork, ev_join;
@@ -491,12 +496,15 @@ void launch_scatter_kernel(rn_ctx *ctx, int n, const float *msgs, const int32_t 
                            const int32_t *rvc, void *acc_out, hipStream_t st, int level,
                            bool fixed) {
     ProfScope prof(ctx, RN_K_SCATTER, n, st);
+    // a work list bound for exactly these rows and this tile shape (else: tiles x box_split)
+    const int32_t *items = PACKED && ctx->sc_items && vox == ctx->sc_vox && n == ctx->sc_rows &&
+                           level == ctx->sc_level ? ctx->sc_items : nullptr;
 #define RN_BOX(RAYS, STEPS, FIXED_, CAP)                                                          \
     hipLaunchKernelGGL((k_scatter_box<PACKED, RAYS, STEPS, FIXED_>),                              \
-                       dim3((n + RAYS - 1) / RAYS, box_split(n, RAYS)), dim3(BLOCK),              \
-                       (CAP) * sizeof(double), st, ctx->p, n, msgs, vox, rvc, acc_out,            \
+                       items ? dim3(ctx->sc_count, 1) : dim3((n + RAYS - 1) / RAYS, box_split(n, RAYS)), \
+                       dim3(BLOCK), (CAP) * sizeof(double), st, ctx->p, n, msgs, vox, rvc, acc_out, \
                        ctx->box_stats, CAP,                                                       \
-                       (const int2 *)(PACKED ? slab_boxes_for(ctx, vox, n, true) : nullptr))
+                       (const int2 *)(PACKED ? slab_boxes_for(ctx, vox, n, true) : nullptr), items)
 #ifndef RN_BOX0_CAP
 #define RN_BOX0_CAP 4096
 #endif
@@ -1089,6 +1097,18 @@ int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int3
     ctx->sb_rows = boxes ? rows : 0;
     ctx->sb_boxes = reinterpret_cast<int2 *>(boxes);
     ctx->sb_valid_lo = ctx->sb_valid_hi = 0;
+    return RN_OK;
+}
+
+int rn_scene_bind_scatter_items(rn_ctx *ctx, const int32_t *vox, int64_t rows, int32_t level,
+                                const int32_t *items, int32_t count) {
+    if (!ctx || rows < 0 || count < 0 || level < 0 || level > 1 || (items && (!vox || count < 1)))
+        return fail(ctx, RN_ERR_INVALID, "bad argument");
+    ctx->sc_vox = items ? vox : nullptr;
+    ctx->sc_items = items;
+    ctx->sc_rows = items ? rows : 0;
+    ctx->sc_level = level;
+    ctx->sc_count = items ? count : 0;
     return RN_OK;
 }
 

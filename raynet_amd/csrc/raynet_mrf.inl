@@ -600,7 +600,8 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
                                                        const int32_t *__restrict__ rvc,
                                                        void *acc_out_raw,
                                                        unsigned *overflow_stats, int BOX_CAP,
-                                                       const int2 *__restrict__ slab_boxes) {
+                                                       const int2 *__restrict__ slab_boxes,
+                                                       const int32_t *__restrict__ items) {
     typedef AccSum<FIXED> Sum;
     typename Sum::acc_t *acc_out = static_cast<typename Sum::acc_t *>(acc_out_raw);
     constexpr int BOX_NB = BOX_RAYS * BOX_STEPS / BLOCK;     // pairs per thread and chunk
@@ -611,7 +612,20 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
     __shared__ int red_cnt[WAVES_PER_BLOCK];
     __shared__ int cnts[BOX_RAYS];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
-    const int r0 = xcd_block<RN_XCD_CHUNK_SCATTER>(blockIdx.x, gridDim.x) * BOX_RAYS;
+    // Work list (rn_scene_bind_scatter_items): one workgroup = `cn` consecutive chunks of one tile,
+    // the list sorted longest first -- a tile of long rays (12 chunks at M = 384) is several
+    // items, a border tile one, and no workgroup is started for chunks no ray of its tile reaches.
+    // Without a list: grid.x = tiles, grid.y workgroups share a tile taking every grid.y-th chunk.
+    int r0, chunk0 = (int)blockIdx.y, chunk_step = (int)gridDim.y, chunk_end = 1 << 20;
+    if (items) {
+        const int item = items[xcd_block<RN_XCD_CHUNK_SCATTER>(blockIdx.x, gridDim.x)];
+        r0 = (item >> 12) * BOX_RAYS;
+        chunk0 = (item >> 6) & 63;
+        chunk_end = chunk0 + (item & 63);
+        chunk_step = 1;
+    } else {
+        r0 = xcd_block<RN_XCD_CHUNK_SCATTER>(blockIdx.x, gridDim.x) * BOX_RAYS;
+    }
     // a wavefront instruction covers RPI rays x BOX_STEPS steps; thread (sub, col) of wave w
     // owns step col of the rays w*RPI + sub + k*STRIDE
     constexpr int RPI = WAVE / BOX_STEPS;
@@ -857,17 +871,18 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
     // (Measured, profiles/r02_exp_scatter_prefetch.txt: keeping the NEXT chunk's pairs in flight
     // while working on the current one -- the LDS box, not the registers, limits this kernel to
     // four waves per SIMD -- changes nothing: 1.46 against 1.43 ms per step.)
-    for (int s0 = blockIdx.y * BOX_STEPS; s0 < maxc; s0 += gridDim.y * BOX_STEPS) {
+    const int s_end = min(maxc, chunk_end * BOX_STEPS);
+    for (int s0 = chunk0 * BOX_STEPS; s0 < s_end; s0 += chunk_step * BOX_STEPS) {
         float m[BOX_NB];
         int v[BOX_NB];
         unsigned okmask;
         load_pairs(s0, m, v, okmask);
         process(s0, m, v, okmask);
     }
-    if (tid == 0 && overflow_stats)
-        atomicAdd(overflow_stats,
-                  (unsigned)((maxc + BOX_STEPS - 1) / BOX_STEPS + gridDim.y - 1 - blockIdx.y) /
-                      gridDim.y);
+    if (tid == 0 && overflow_stats) {
+        const int live = max(0, (s_end + BOX_STEPS - 1) / BOX_STEPS - chunk0);      // chunks from chunk0 on
+        atomicAdd(overflow_stats, (unsigned)((live + chunk_step - 1) / chunk_step));
+    }
 }
 
 // deterministic scatter for rows the box kernel is not used on: every (ray, voxel) pair adds

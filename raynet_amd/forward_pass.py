@@ -1084,6 +1084,32 @@ class RayNetForwardPass(ForwardPass):
             cur.wait_stream(self._side_stream)
             cur.wait_stream(self._copy_stream)
 
+    def _scatter_work_list(self, plan, ctx):
+        """From a plan's second pass on (the first one's traversal left the voxel counts) the box
+        scatter takes a work list -- a tile's live chunks in pieces, longest first -- instead of
+        tiles x a fixed split: a shard of an eight-rank run has ~1500 tiles whose longest (12
+        chunks) IS the launch otherwise.  The counts depend on cameras and shard only, so the
+        list is built once per plan and tile level (one host synchronisation) and re-bound when
+        another driver used the shared context in between."""
+        if not hasattr(ctx, "bind_scatter_items"):
+            return
+        use = self.options.scatter_items and plan["patch_rows"] and plan["passes"] >= 1 and \
+            len(plan["groups"]) == 1 and plan["vox"].shape[0] == plan["rvc"].shape[0]
+        level = ctx.scatter_state()[0] if use else 2
+        if not use or level > 1:
+            if getattr(ctx, "_scatter_items", None) is not None:
+                ctx.bind_scatter_items(None)
+            return
+        if plan.get("items_level") != level:
+            import os
+            plan["items"] = ctx.bind_scatter_items(
+                plan["vox"], plan["rvc"], level,
+                target_items=int(os.environ.get("RAYNET_SCATTER_TARGET", "2048")))    # (A/B knob; profiles/r04_exp_scatter_items.txt)
+            plan["items_level"] = level
+            plan["graphs"] = {}                  # (a captured step has the old launch shape in it)
+        elif plan["items"] is not None and not ctx.scatter_items_bound(plan["items"]):
+            ctx.bind_scatter_items(plan["vox"], level=level, items=plan["items"])
+
     def _capturable(self, plan, ctx, dist):
         """Whether this pass may be recorded into a HIP graph: a CUDA device, a transport whose
         collectives are stream work (RCCL; gloo runs on the host), the scatter's adaptive tile
@@ -1144,6 +1170,7 @@ class RayNetForwardPass(ForwardPass):
         if plan["fast"] is not None:
             self._epilogue_buffers(plan, refs, H, W, dev, world, rank, dist is not None)
             V = len(refs)
+            self._scatter_work_list(plan, ctx)
             # which pinned set this pass writes.  "view" / "auto": the two sets in turns, so that a
             # pass's maps outlive the next pass; "auto" looks, before it overwrites a set, whether
             # the caller still holds a map (or a view of one) of the pass before last -- then the

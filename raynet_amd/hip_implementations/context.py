@@ -54,6 +54,33 @@ def _chk(t, dtype, min_numel=0, name="tensor", optional=False, align=4):
     return t
 
 
+def scatter_work_list(rvc, M, level=0, target_items=2048):
+    """int32 items `tile << 12 | first chunk << 6 | chunks` for the LDS-box scatter at tile
+    `level` (0: 128 rays x 32 steps, 1: 256 x 16) from the rays' voxel counts [rows]: a tile's
+    LIVE chunks (up to its longest sending ray; rays with <= 1 voxels send nothing, mrf_np.py:300)
+    in items of U chunks, U such that the launch has about `target_items` workgroups -- a tile of
+    long rays becomes several items, a border tile one, a tile no ray of which sends anything none
+    -- sorted longest first, tiles in order within a length.  None when nothing is live."""
+    tile, steps = (128, 32) if level == 0 else (256, 16)
+    c = rvc.to(torch.int64).clamp(max=M)
+    c = torch.where(c <= 1, torch.zeros_like(c), c)
+    pad = (-c.numel()) % tile
+    if pad:
+        c = torch.cat([c, torch.zeros((pad,), dtype=c.dtype, device=c.device)])
+    nch = (c.view(-1, tile).max(1).values + steps - 1) // steps          # live chunks per tile
+    total = int(nch.sum().item())
+    if total == 0:
+        return None
+    U = int(min(63, max(1, -(-total // int(target_items)))))
+    per_tile = (nch + U - 1) // U                                        # items per tile
+    tile_of = torch.repeat_interleave(torch.arange(len(nch), device=c.device), per_tile)
+    first = torch.cumsum(per_tile, 0) - per_tile
+    begin = (torch.arange(len(tile_of), device=c.device) - first[tile_of]) * U
+    cnt = torch.minimum(torch.full_like(begin, U), nch[tile_of] - begin)
+    order = torch.sort(-cnt, stable=True).indices
+    return ((tile_of << 12) | (begin << 6) | cnt)[order].to(torch.int32).contiguous()
+
+
 def to_device(x, dtype=None, device="cuda"):
     """The reference's `to_gpu` / all_arrays_to_gpu (cuda_implementations/utils.py:11-22):
     NumPy arrays are uploaded, device tensors pass through untouched."""
@@ -169,6 +196,31 @@ class HipContext(object):
         self._slab_boxes = (table, vox)
         self._check(self.lib.rn_scene_bind_slab_boxes(self._h, _ptr(vox), rows, _ptr(table)))
         return table
+
+    def bind_scatter_items(self, vox, rvc=None, level=0, target_items=2048, items=None):
+        """Work list of the LDS-box scatter over ALL rows of `vox` ([rows][M]; None unbinds), built
+        from the rays' voxel counts `rvc` [rows] by scatter_work_list (or `items`: a list built
+        before, to bind again -- contexts are shared, the binding is the last caller's).  One host
+        synchronisation (the item count) per build; the list depends on the counts only, i.e. on
+        cameras and shard, not on a pass (rn_scene_bind_scatter_items)."""
+        if vox is None:
+            self._check(self.lib.rn_scene_bind_scatter_items(self._h, None, 0, 0, None, 0))
+            self._scatter_items = None
+            return None
+        rows = vox.numel() // self.M
+        if items is None:
+            items = scatter_work_list(rvc, self.M, level, target_items)
+        if items is None or items.numel() == 0:
+            return self.bind_scatter_items(None)
+        _chk(items, torch.int32, 1, "scatter items")
+        self._scatter_items = (items, vox, level)
+        self._check(self.lib.rn_scene_bind_scatter_items(self._h, _ptr(vox), rows, int(level),
+                                                         _ptr(items), int(items.numel())))
+        return items
+
+    def scatter_items_bound(self, items):
+        cur = getattr(self, "_scatter_items", None)
+        return cur is not None and cur[0] is items
 
     def slab_boxes_bound_to(self, vox):
         sb = getattr(self, "_slab_boxes", None)

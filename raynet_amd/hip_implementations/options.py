@@ -39,6 +39,9 @@ class PathOptions:
     #                                   size instead of the rows as they lie (None); with sweep_xcd_chunk
     #                                   rays (0: the library's 2048) side by side on one XCD
     sweep_xcd_chunk: int = 0
+    scatter_items: bool = True        # the box scatter takes a work list built from the rays' voxel
+    #                                   counts (a tile's live chunks in pieces, longest first) from a
+    #                                   plan's second pass on, instead of tiles x a fixed split
     slab_boxes: bool = True           # the scatters merge the traversal's slab boxes instead of scanning
     plan_path: bool = True            # one C call per phase of a pass (rn_scene_run) when the pass qualifies
     depth_head: bool = True           # one GPU: all images but the last decoded by one launch
@@ -92,6 +95,7 @@ class PathOptions:
         "RAYNET_SWEEP_TILE": ("sweep_tile", _tile),
         "RAYNET_SWEEP_XCD_CHUNK": ("sweep_xcd_chunk", int),
         "RAYNET_SLAB_BOXES": ("slab_boxes", _flag),
+        "RAYNET_SCATTER_ITEMS": ("scatter_items", _flag),
         "RAYNET_PLAN_PATH": ("plan_path", _flag),
         "RAYNET_DEPTH_HEAD": ("depth_head", _flag),
         "RAYNET_DIRECT_MAPS": ("direct_maps", _flag),

@@ -124,3 +124,36 @@ def test_forward_pass_object_carries_its_options():
     assert fp.options.ray_tile is None and fp.options.deterministic
     fp.deterministic = False
     assert not fp.options.deterministic
+
+
+def test_scatter_work_list_covers_every_live_chunk_once():
+    """hip_implementations/context.py scatter_work_list: items `tile << 12 | first << 6 | chunks`
+    cover every chunk below a tile's longest sending ray exactly once, none beyond it, none for
+    tiles whose rays send nothing (count <= 1, mrf_np.py:300), longest items first."""
+    import torch
+    from raynet_amd.hip_implementations.context import scatter_work_list
+    rng = np.random.default_rng(0)
+    for rows, M, level in ((1000, 384, 0), (5000, 768, 1), (130, 96, 0)):
+        rvc = torch.from_numpy(rng.integers(0, M + 30, rows).astype(np.int32))
+        rvc[:300] = 1
+        tile, steps = (128, 32) if level == 0 else (256, 16)
+        c = np.minimum(rvc.numpy(), M)
+        c = np.where(c <= 1, 0, c)
+        c = np.concatenate([c, np.zeros((-rows) % tile, np.int64)])
+        nch = (c.reshape(-1, tile).max(1) + steps - 1) // steps
+        for target in (8, 64, 4096):
+            items = scatter_work_list(rvc, M, level, target)
+            if nch.sum() == 0:
+                assert items is None
+                continue
+            it = items.numpy()
+            cover = np.zeros((len(nch), 64), np.int64)
+            for v in it:
+                t, b, n = v >> 12, (v >> 6) & 63, v & 63
+                assert n >= 1
+                cover[t, b:b + n] += 1
+            for t in range(len(nch)):
+                assert (cover[t, :nch[t]] == 1).all() and (cover[t, nch[t]:] == 0).all()
+            assert (np.diff(it & 63) <= 0).all()
+            assert len(it) <= max(int(nch.sum()), 1)
+    assert scatter_work_list(torch.ones(300, dtype=torch.int32), 96, 0) is None
