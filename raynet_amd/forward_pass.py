@@ -638,6 +638,8 @@ class RayNetForwardPass(ForwardPass):
         self._plan = plan = None                     # release the old buffers first
         if hasattr(ctx, "bind_slab_boxes"):
             ctx.bind_slab_boxes(None)                # (the binding holds the old list buffer)
+        if getattr(ctx, "_scatter_items", None) is not None:
+            ctx.bind_scatter_items(None)             # (... and so does the scatter's work list)
         plan = dict(key=key, ptrs=ptrs, scene=scene, cams=cams, prior=self._prior(), dirty=False,
                     cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
                     balance=balance, shards=shards, npad=npad, shared=shared,
@@ -1268,6 +1270,8 @@ class RayNetForwardPass(ForwardPass):
                 yield a.reshape(W, H).T
             self._pass_complete = True
             return
+        if getattr(ctx, "_scatter_items", None) is not None:
+            ctx.bind_scatter_items(None)     # (a work list is the plan path's; contexts are shared)
         for out in self._run_granular(scene, refs, bank, ctx, plan, dist, rank, world):
             yield out
 

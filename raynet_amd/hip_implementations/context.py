@@ -218,6 +218,14 @@ class HipContext(object):
                                                          _ptr(items), int(items.numel())))
         return items
 
+    def _drop_foreign_items(self, vox):
+        """A work list bound for another tensor must not meet a launch whose buffer happens to sit
+        at the address (and have the row count) the list was built for: unbind unless `vox` IS the
+        tensor it describes."""
+        cur = getattr(self, "_scatter_items", None)
+        if cur is not None and cur[1] is not vox:
+            self.bind_scatter_items(None)
+
     def scatter_items_bound(self, items):
         cur = getattr(self, "_scatter_items", None)
         return cur is not None and cur[0] is items
@@ -621,6 +629,7 @@ class HipContext(object):
     def scene_bp_sweep(self, Sr, vox, rvc, acc_in, msgs, acc_part, first_sweep=False,
                        patch_rows=False, uniform_acc=False):
         n = self._chk_rows(Sr, vox, rvc, msgs, acc_in, acc_part)
+        self._drop_foreign_items(vox)
         self._check(self.lib.rn_scene_bp_sweep(self._h, n, _ptr(Sr), _ptr(vox), _ptr(rvc),
                                                _ptr(acc_in), _ptr(msgs), _ptr(acc_part),
                                                (1 if first_sweep else 0) | (2 if uniform_acc else 0),
@@ -629,6 +638,7 @@ class HipContext(object):
     def scene_bp_sweep_fixed(self, Sr, vox, rvc, acc_in, msgs, acc_part_fixed, first_sweep=False,
                              patch_rows=False, uniform_acc=False):
         n = self._chk_rows(Sr, vox, rvc, msgs, acc_in, acc_part_fixed, torch.int64)
+        self._drop_foreign_items(vox)
         self._check(self.lib.rn_scene_bp_sweep_fixed(
             self._h, n, _ptr(Sr), _ptr(vox), _ptr(rvc), _ptr(acc_in), _ptr(msgs),
             _ptr(acc_part_fixed), (1 if first_sweep else 0) | (2 if uniform_acc else 0),
