@@ -1221,7 +1221,8 @@ class RayNetForwardPass(ForwardPass):
             # (a pass whose launches or exchanges are bracketed by events runs eagerly)
             eager = self.trace is not None or getattr(ctx, "prof_active", False) or \
                 self.options.capture == "off"
-            graph = None if eager else plan["graphs"].get(slot)
+            gkey = (slot, self.bp_iterations)       # (what a recorded step has baked in)
+            graph = None if eager else plan["graphs"].get(gkey)
             if graph is None and not eager and self._capturable(plan, ctx, dist):
                 # the whole step -- phases, exchanges, epilogue -- as ONE graph (per host set):
                 # no interpreter and no launch overhead between its launches from now on
@@ -1229,7 +1230,7 @@ class RayNetForwardPass(ForwardPass):
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         self._run_plan_path(plan, ctx, refs, dist, world, slot, captured=True)
-                    plan["graphs"][slot] = graph
+                    plan["graphs"][gkey] = graph
                 except Exception as e:        # a transport / runtime that cannot be captured
                     import warnings
                     warnings.warn("raynet_amd: step capture failed (%s); eager schedule" % (e,))

@@ -430,6 +430,13 @@ def test_captured_step_replays_the_eager_pass(torch):
             if sum(seen) >= 4:
                 break
         assert seen[-1] and seen[-2] and len(fp._plan["graphs"]) == 2       # both host sets
+        # another iteration count on the same plan is another step: never the recorded one's replay
+        fp.bp_iterations = T - 1
+        fewer = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+        assert not np.array_equal(fewer, first)
+        fp.bp_iterations = T
+        again = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
+        assert fp.captured and np.array_equal(again, first)
         msgs = fp.messages[1].cpu().numpy()
         eager = cls(bank, gp, "sample_in_bbox", (H, W), 0, bp_iterations=T,
                     options=PathOptions(deterministic=True, capture="off"))
