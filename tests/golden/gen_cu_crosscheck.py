@@ -2,9 +2,13 @@
 """Cross-check vectors for the CUDA flavour of the path (a1, a2, a4 and the
 fused K1/K2 composition), for which the reference has NO test and no CPU twin.
 
-HONEST LABEL.  The six .cu files cannot be built as intended here (no nvcc, no
-CUDA headers), so this is NOT a reference build and nothing from it lands in
-oracle/_ref.  What this script does instead, in the build container only:
+HONEST LABEL.  This is NOT a reference build and nothing from it lands in
+oracle/_ref: it runs the device functions as HOST code behind stand-in macros
+(rounds 1-4 believed the .cu files unbuildable without nvcc; they are not --
+oracle/build_ref_cu.py compiles them unchanged with hipcc for gfx950, and
+tests/golden/ref_cu_gfx950.npz + tests/test_reference_kernels.py are the pin;
+these vectors remain as a CPU-side second opinion).  What this script does, in
+the build container only:
   * reads the .cu files where they lie under /root/reference,
   * fills the $placeholders exactly as cuda_implementations/raynet_fp.py:230-248
     does (string.Template.substitute),
@@ -12,8 +16,7 @@ oracle/_ref.  What this script does instead, in the build container only:
     (g++), appends a thin extern "C" caller, builds into a /tmp scratch dir,
   * runs the device functions on seeded inputs and stores inputs + outputs.
 The vectors are therefore "the reference's device-function text executed on a
-CPU".  DESIGN.md states that parity for a1/a2 is unpinned by the reference's
-own tests and that these vectors are the supplementary evidence.  No reference
+CPU": supplementary evidence next to the GPU run of the real kernels.  No reference
 text is written into this repository; only arrays are.
 
 Host-execution caveats: bbox/grid literals become double

@@ -8,6 +8,7 @@ arg-max near-ties."""
 import numpy as np
 import pytest
 
+from bp_truth import bp_truth_f64 as _bp_truth_f64
 from conftest import assert_depth_flips_are_near_ties, load_cases
 
 pytestmark = pytest.mark.gpu
@@ -247,33 +248,6 @@ def test_bp_backend_vs_reference_numpy(torch, oracle_mod, case):
                           grid_shape=c["grid"])
     acc_o, msgs_o = o.belief_propagation(c["S"], c["rvi"], c["rvc"], np.zeros_like(c["S"]))
     assert np.all(np.abs(msgs - msgs_o) <= logit_tol(msgs_o))
-
-
-def _bp_truth_f64(S, rvi, rvc, acc, msgs):
-    """One BP sweep in float64 on the same fp32 inputs: the value
-    both fp32 implementations approximate.  Returns messages and, per entry, the
-    amplification of an ulp-of-W error in the reference's (cumsum1 - cumsum2)."""
-    out = np.zeros(msgs.shape, np.float64)
-    cancel = np.zeros(msgs.shape, np.float64)
-    lo, hi = np.float32(1e-5), np.float32(1 - 1e-5)
-    for r in range(len(rvc)):
-        c = int(rvc[r])
-        if c <= 1:
-            continue
-        s = np.clip(S[r, :c], lo, hi).astype(np.float64)
-        s /= s.sum()
-        idx = tuple(rvi[r, :c].T)
-        mu = acc[idx].astype(np.float64) - msgs[r, :c]
-        o = np.clip(1.0 / (1.0 + np.exp(-mu)), np.float32(1e-4), np.float32(1 - 1e-4))
-        T = np.concatenate([[1.0], np.cumprod(1 - o)[:-1]])
-        w = o * T * s
-        C = np.concatenate([[0.0], np.cumsum(w)[:-1]])
-        suf = np.cumsum(w[::-1])[::-1] - w
-        pos = C + T * s
-        neg = C + suf / (1 - o)
-        out[r, :c] = np.log(pos) - np.log(neg)
-        cancel[r, :c] = w.sum() / ((1 - o) * neg)
-    return out, cancel
 
 
 def test_bp_single_sweep_against_float64_truth(torch, oracle_mod):
