@@ -244,7 +244,8 @@ int rn_scene_bind_slab_boxes(rn_ctx *ctx, const int32_t *vox, int64_t rows, int3
  * exactly one item).  A scatter launch over exactly these rows at that level takes the list;
  * any other launch -- and every launch after items == NULL -- deals tiles x chunks out itself.
  * The list depends on the rays' voxel counts only (ray_tracing.pyx:64-199), not on messages: it
- * is built once per scene and shard.  Speed only: the sums are the same. */
+ * is built once per scene and shard.  Speed only: the sums are the same.  The tile field has 19
+ * bits: rows beyond 2^19 tiles of the level are refused (RN_ERR_INVALID). */
 int rn_scene_bind_scatter_items(rn_ctx *ctx, const int32_t *vox, int64_t rows, int32_t level,
                                 const int32_t *items, int32_t count);
 

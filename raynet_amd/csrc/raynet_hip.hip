@@ -1104,6 +1104,11 @@ int rn_scene_bind_scatter_items(rn_ctx *ctx, const int32_t *vox, int64_t rows, i
                                 const int32_t *items, int32_t count) {
     if (!ctx || rows < 0 || count < 0 || level < 0 || level > 1 || (items && (!vox || count < 1)))
         return fail(ctx, RN_ERR_INVALID, "bad argument");
+    // an item is `tile << 12 | first << 6 | count` in 32 bits: 19 bits of tile index
+    if (items && (rows + (level == 0 ? 127 : 255)) / (level == 0 ? 128 : 256) > (int64_t(1) << 19))
+        return fail(ctx, RN_ERR_INVALID, "rn_scene_bind_scatter_items: %lld rows are more than "
+                    "2^19 tiles of level %d; use the tiles x split launch (no work list)",
+                    (long long)rows, level);
     ctx->sc_vox = items ? vox : nullptr;
     ctx->sc_items = items;
     ctx->sc_rows = items ? rows : 0;
@@ -1232,6 +1237,7 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
                                   int32_t *rvc, float *Sr, float *ray_segments, void *stream,
                                   float *msgs_fold, float prior, float *zero_fold = nullptr,
                                   int sweep_xcd_chunk = 0) {
+    if (ctx && n == 0 && n_images >= 1) return RN_OK;   /* a rank without rays: pointers may be null */
     if (!ctx || n_images < 1 || n < 0 || rows_per_image < n || !ray_idxs || !features_views ||
         !cameras || !vox || !rvc || !Sr)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
@@ -1331,9 +1337,9 @@ int rn_scene_prepare_all(rn_ctx *ctx, int32_t n_images, int32_t n, int64_t rows_
 
 int rn_scene_count_voxels(rn_ctx *ctx, int32_t n_images, int32_t n, const int32_t *ray_idxs,
                           const float *cameras, int32_t *rvc, void *stream) {
+    if (ctx && n == 0 && n_images >= 1) return RN_OK;   /* empty launch: pointers may be null */
     if (!ctx || n_images < 1 || n < 0 || !ray_idxs || !cameras || !rvc)
         return fail(ctx, RN_ERR_INVALID, "bad argument");
-    if (n == 0) return RN_OK;
     const int N = ctx->p.N;
     const int cam_stride = 12 * N + 12 + 4;
     ProfScope prof(ctx, RN_K_TRAVERSE, n * n_images, S(stream));

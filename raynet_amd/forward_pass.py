@@ -30,8 +30,6 @@ sharded contiguously over the ranks; each rank scatters into its own zeroed
 accumulator and one all-reduce (RCCL) per BP iteration merges them before the
 prior is added once.
 """
-import sys
-
 import numpy as np
 import torch
 
@@ -74,23 +72,11 @@ def _backend_of(dist):
         return ""
 
 
-def map_owner(k, n_images, world, mode):
-    """Rank that assembles image k's depth map (PathOptions.gather): "owner" deals the images out
-    in contiguous blocks -- monotone in k, so a rank's depth rows are already ordered by
-    destination rank, what an all-to-all wants -- "rank0" gives rank 0 all of them."""
-    return (k * world) // n_images if mode == "owner" else 0
-
-
-def _all_to_all_rows(dist, out, inp, out_split, in_split):
-    """all_to_all_single over the ranks' depth rows.  RCCL moves device memory; a transport that
-    only takes host tensors (gloo, the functional tests with several ranks on one GPU) is staged
-    through the host."""
-    if inp.is_cuda and _backend_of(dist) == "gloo":
-        o = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(o, inp.cpu(), out_split, in_split)
-        out.copy_(o)
-    else:
-        dist.all_to_all_single(out, inp, out_split, in_split)
+def map_owner(k, n_images, world):
+    """Rank that assembles image k's depth map when the rays are sharded (the reference needs a
+    map once, forward_pass.py:739-744): the images dealt out in contiguous blocks -- monotone in
+    k, so a rank's depth rows are already ordered by destination."""
+    return (k * world) // n_images
 
 
 def sweep_direction(H, W, images):
@@ -665,6 +651,9 @@ class RayNetForwardPass(ForwardPass):
         # buffers): every image casts the same ray list in one launch, all columns resident
         fast_ok = (opt.plan_path and hasattr(ctx, "scene_run") and shared is not None and V > 0 and
                    not self.rays_batch and len(plan["groups"]) == 1 and not self.reference_quirks)
+        if dist is not None and not (dev.type == "cuda" and (H * W) % 4 == 0 and
+                                     hasattr(ctx, "stitch_rows")):
+            fast_ok = False     # the owners' maps are put together by rn_stitch_rows (float4 stores)
         order = None
         if fast_ok and not patch_rows and opt.sweep_reorder:
             modes = {sweep_direction(H, W, [scene.get_image(v) for v in views_of[r]]) for r in refs}
@@ -709,35 +698,25 @@ class RayNetForwardPass(ForwardPass):
 
     # -- where the maps land -------------------------------------------------------------------
     def _host_set(self, V, HW, cuda):
-        """One set of pinned host maps and its ROOT arrays (one flat ndarray per image).  What a
-        pass yields are fresh views of the roots; every view (and every view of a view) keeps its
-        root alive and counted, which is how _maps_held sees a caller still holding one."""
+        """One set of pinned host maps: the tensor and one flat ndarray view per image."""
         h = torch.empty((V, HW), dtype=torch.float32, pin_memory=cuda)
         return h, [h[k].numpy() for k in range(V)]
 
-    @staticmethod
-    def _root_counts(roots):
-        return [sys.getrefcount(a) for a in roots]
-
-    def _maps_held(self, plan, slot):
-        return any(c > plan["root_rc"] for c in self._root_counts(plan["host_root"][slot]))
-
     def _epilogue_buffers(self, plan, refs, H, W, dev, world, rank, collective):
         """Plan-owned output side: per-image events, the device-side pixel-order maps, and TWO
-        sets of pinned host maps used alternately -- a pass allocates nothing.  What a pass
-        yields (PathOptions.maps): views of its set, valid until the second-next pass over the
-        same plan ("view"); fresh arrays like the reference's `.get()`, forward_pass.py:739-744
-        ("copy"); or views until a caller is SEEN to keep one across passes -- that caller keeps
-        the memory, the plan takes a new set and hands out copies from then on ("auto")."""
+        sets of pinned host maps -- a pass allocates nothing.  What a pass yields
+        (PathOptions.maps): fresh arrays like the reference's `.get()`, forward_pass.py:739-744
+        ("copy", the default: one set is enough), or views of the two sets used in turns, valid
+        until the second-next pass over the same plan ("view")."""
         if "host" in plan:
             return
         cuda = dev.type == "cuda"
         V, HW = len(refs), H * W
-        sets = [self._host_set(V, HW, cuda) for _ in range(2)]
+        copy_maps = self.options.maps == "copy"
+        sets = [self._host_set(V, HW, cuda) for _ in range(1 if copy_maps else 2)]
         plan["host"] = [a for a, _ in sets]
         plan["host_root"] = [b for _, b in sets]
-        plan["root_rc"] = max(self._root_counts(plan["host_root"][0])) if V else 0
-        plan["copy_maps"] = self.options.maps == "copy"
+        plan["copy_maps"] = copy_maps
         plan["graphs"] = {}
         plan["passes"] = 0
         if "maps_dev" not in plan:
@@ -751,86 +730,38 @@ class RayNetForwardPass(ForwardPass):
             if self._side_stream is None:
                 self._side_stream, self._copy_stream = _side_streams(dev)
         npad, lists, bounds = plan["npad"], plan["lists"], plan["bounds"]
-        gather = self.options.gather if collective else "all"
-        plan["owners"] = None if gather == "all" else [map_owner(k, V, world, gather) for k in range(V)]
+        plan["owners"] = [map_owner(k, V, world) for k in range(V)] if collective else None
         if not collective:
             # rows -> pixels: one index per image (rays that were filtered out stay 0)
             plan["pix"] = [lists[r].long() for r in refs] if (
                 plan["patch_rows"] or self._filter_out_rays) else None
             return
-
-        def stitch_index(k, r):
-            """per pixel of image k: q * npad + row within rank q's block (world * npad: no ray)"""
-            src = torch.full((HW,), world * npad, dtype=torch.int64, device=dev)
-            rays, cuts = lists[r].long(), bounds[k]
-            for q in range(world):
-                lo_q, hi_q = cuts[q], cuts[q + 1]
-                src[rays[lo_q:hi_q]] = q * npad + torch.arange(hi_q - lo_q, dtype=torch.int64,
-                                                               device=dev)
-            return src
-
-        plan["a2a"] = None
+        # With a process group (the plan path then requires rn_stitch_rows, _build_plan): image
+        # k's map is assembled on ONE rank.  ONE depth launch over all of a rank's rows, ONE
+        # all-gather that hands every rank everybody's rows (5 MB more per rank and step than an
+        # all-to-all of only what an owner needs, on links that are idle at that point -- and
+        # the one of the two that RCCL captures into a HIP graph on this runtime), and on an
+        # owner ONE rn_stitch_rows launch that puts its images into pixel order and writes the
+        # pinned host maps across PCIe itself.
         owners = plan["owners"]
-        if owners is not None and cuda and HW % 4 == 0 and hasattr(self._ctx, "stitch_rows") and \
-                plan["fast"] is not None:
-            # Owner-only epilogue (the map is needed ONCE, forward_pass.py:739-744): ONE depth
-            # launch over all of the rank's rows, ONE all-to-all that takes every rank's rows of
-            # image k to k's owner (the owners are monotone in k, so plan["depth"] already is in
-            # destination order), and on an owner ONE rn_stitch_rows launch that puts its images
-            # into pixel order and writes the pinned host maps across PCIe itself.
-            mine = [k for k in range(V) if owners[k] == rank]
-            n_own = len(mine)
-            # how the rows travel (PathOptions.rows_exchange): "all_to_all" sends a rank's rows of
-            # image k to k's owner only (blk = my images' rows of one source rank); "all_gather"
-            # (default) hands every rank everybody's rows and the owners pick theirs -- 5 MB more
-            # per rank and step on links that are idle at that point, and the one of the two
-            # RCCL captures into a HIP graph on this runtime (an all-to-all inside a capture
-            # takes the process down: tools/r04_rccl_probe.py)
-            a2a = self.options.rows_exchange == "all_to_all"
-            blk = n_own * npad if a2a else V * npad     # one source rank's block in `recv`
-            recv = torch.zeros((world * blk + 1,), dtype=torch.float32, device=dev)
-            table = None
-            if n_own:
-                idx = torch.empty((n_own, HW), dtype=torch.int32, device=dev)
-                for j, k in enumerate(mine):
-                    st = stitch_index(k, refs[k])
-                    at = (st // npad) * blk + (j if a2a else k) * npad + st % npad
-                    idx[j] = torch.where(st == world * npad, torch.full_like(at, world * blk),
-                                         at).to(torch.int32)
-                table = idx.reshape(-1)
-            plan["a2a"] = dict(mine=mine, recv=recv, table=table, all_to_all=a2a,
-                               out_split=[blk] * world,
-                               in_split=[npad * sum(1 for o in owners if o == d)
-                                         for d in range(world)])
-            return
-        # every rank assembles every map (gather="all", and back ends without rn_stitch_rows).
-        # per image: the ranks' row blocks side by side (+ one zero for pixels without a
-        # ray) and the index that puts them into pixel order
-        plan["gathered"] = [torch.zeros((world * npad + 1,), dtype=torch.float32, device=dev)
-                            for _ in range(V)]
-        stitch = [stitch_index(k, r) for k, r in enumerate(refs)]
-        plan["stitch"] = stitch
-        # (rn_stitch_rows: the same table as 32-bit indices -- stitch and copy in one launch)
-        plan["stitch32"] = [t.to(torch.int32) for t in stitch] if cuda else None
-        # groups of images that share ONE depth launch, ONE all-gather and ONE stitch launch
-        # (a group's rows are contiguous in the scene-wide buffers, its host maps too)
-        gsz = self.options.rank_group
-        plan["rank_groups"] = None
-        if cuda and gsz > 0 and HW % 4 == 0 and hasattr(self._ctx, "stitch_rows") and \
-                plan["fast"] is not None:
-            groups = [(a, min(a + gsz, V)) for a in range(0, V, gsz)]
-            gathered, tables = [], []
-            for a, b in groups:
-                blk = (b - a) * npad                      # one rank's rows of the group
-                gathered.append(torch.zeros((world * blk + 1,), dtype=torch.float32, device=dev))
-                idx = torch.empty(((b - a), HW), dtype=torch.int32, device=dev)
-                for k in range(a, b):
-                    q, j = stitch[k] // npad, stitch[k] % npad        # (rank, row) per pixel
-                    at = q * blk + (k - a) * npad + j
-                    idx[k - a] = torch.where(stitch[k] == world * npad,
-                                             torch.full_like(at, world * blk), at).to(torch.int32)
-                tables.append(idx.reshape(-1))
-            plan["rank_groups"], plan["gathered_grp"], plan["stitch32_grp"] = groups, gathered, tables
+        mine = [k for k in range(V) if owners[k] == rank]
+        blk = V * npad                               # one source rank's block in `recv`
+        recv = torch.zeros((world * blk + 1,), dtype=torch.float32, device=dev)
+        table = None
+        if mine:
+            idx = torch.empty((len(mine), HW), dtype=torch.int32, device=dev)
+            for j, k in enumerate(mine):
+                # per pixel of image k: where its ray's depth sits in `recv` (the zero behind
+                # the blocks for a pixel without a ray)
+                at = torch.full((HW,), world * blk, dtype=torch.int64, device=dev)
+                rays, cuts = lists[refs[k]].long(), bounds[k]
+                for q in range(world):
+                    lo_q, hi_q = cuts[q], cuts[q + 1]
+                    at[rays[lo_q:hi_q]] = q * blk + k * npad + torch.arange(
+                        hi_q - lo_q, dtype=torch.int64, device=dev)
+                idx[j] = at.to(torch.int32)
+            table = idx.reshape(-1)
+        plan["rows"] = dict(mine=mine, recv=recv, table=table)
 
     def _mark(self, name, begin):
         """bench.py --gpus N: a pair of events around every exchange of an eager pass
@@ -840,34 +771,17 @@ class RayNetForwardPass(ForwardPass):
             ev.record()
             self.trace.append((name, begin, ev))
 
-    def _emit_image(self, plan, k, st, dist, world, slot):
-        """Image k's depth rows (just enqueued on the current stream) -> pixel order -> pinned
-        host memory, on side streams: under the depth sweep of image k + 1.  Several ranks:
-        the all-gather of the ranks' row blocks (every rank sends only its own rows) runs on
-        the first side stream, the copy to the host on the second, so that image k + 1's
-        exchange does not wait for image k's PCIe transfer."""
+    def _emit_image(self, plan, k, st, slot):
+        """One GPU, no process group: image k's depth rows (just enqueued on the current stream)
+        -> pixel order -> pinned host memory, on side streams: under the depth sweep of image
+        k + 1 (the reorder on the first side stream, the copy to the host on the second)."""
         host = plan["host"][slot][k]
-        rows = plan["depth"][st["row0"]:st["row0"] + (plan["npad"] if dist is not None else st["n"])]
+        rows = plan["depth"][st["row0"]:st["row0"] + st["n"]]
         side, copy = self._side_stream, self._copy_stream
         plan["ev_ready"][k].record()
         with torch.cuda.stream(side):
             side.wait_event(plan["ev_ready"][k])
-            if dist is not None:
-                g = plan["gathered"][k]
-                self._mark("gather", True)
-                dist.all_gather_into_tensor(g[:-1], rows)
-                self._mark("gather", False)
-                if plan.get("stitch32") is not None and hasattr(self._ctx, "stitch_rows") and \
-                        host.data_ptr() % 16 == 0:
-                    # pixel order AND the way to the host in one launch: the kernel writes the
-                    # pinned map itself (no second stream, no event hop, no copy)
-                    self._ctx.stitch_rows(g, plan["stitch32"][k], host)
-                    plan["ev_done"][k].record()
-                    plan["wait_ev"][k] = plan["ev_done"][k]
-                    return
-                torch.index_select(g, 0, plan["stitch"][k], out=plan["maps_dev"][k])
-                src = plan["maps_dev"][k]
-            elif plan["pix"] is not None:
+            if plan["pix"] is not None:
                 plan["maps_dev"][k].index_copy_(0, plan["pix"][k], rows)
                 src = plan["maps_dev"][k]
             else:
@@ -925,58 +839,6 @@ class RayNetForwardPass(ForwardPass):
             self._mark("exchange", False)
         ctx.scene_run(fast, _lib.RN_RUN_COMBINE, it)
 
-    def _pieces(self, plan, ctx, V):
-        """PathOptions.exchange_pieces = K > 1: the images in K contiguous groups, each with its
-        own partial accumulator and a copy of the C plan whose SWEEP phase covers the group's
-        rows and scatters into that partial (HipContext.scene_plan_piece)."""
-        K = min(int(self.options.exchange_pieces), V)
-        if K <= 1 or plan["fast"] is None or not hasattr(ctx, "scene_plan_piece"):
-            return None
-        if "pieces" not in plan:
-            G, dev, fixed = ctx.acc_size(), ctx.device, plan["fixed"]
-            cuts = [V * p // K for p in range(K + 1)]
-            parts = torch.zeros((K, G), dtype=torch.float32, device=dev)
-            parts_fixed = torch.zeros((K, G), dtype=torch.int64, device=dev) if fixed else None
-            structs = [[ctx.scene_plan_piece(plan["fast"], cuts[p], cuts[p + 1] - cuts[p], parts[p], e,
-                                             parts_fixed[p] if fixed else None) for e in (0, 1)]
-                       for p in range(K)]
-            plan["pieces"] = dict(K=K, parts=parts, parts_fixed=parts_fixed, structs=structs,
-                                  ev=[torch.cuda.Event() for _ in range(K)]
-                                  if dev.type == "cuda" else None)
-            if self._side_stream is None and dev.type == "cuda":
-                self._side_stream, self._copy_stream = _side_streams(dev)
-        return plan["pieces"]
-
-    def _sweep_in_pieces(self, plan, ctx, dist, pc, it):
-        """BP iteration `it` (>= 1) group by group: a group's k_bp + scatter into ITS partial, then
-        the all-reduce of that partial on the side stream -- under the next group's kernels; the
-        accumulator is the sum of the K reduced partials (the prior is added where it is read,
-        once, as ever).  What it buys and what it costs: DESIGN.md section 8 -- K all-reduces of
-        the FULL accumulator size instead of one, of which the last is exposed as before."""
-        K, fixed = pc["K"], plan["fixed"]
-        out = plan["acc_b" if it & 1 else "acc_a"]
-        bufs = pc["parts_fixed"] if fixed else pc["parts"]
-        side = self._side_stream
-        for p in range(K):
-            ctx.scene_run(pc["structs"][p][it & 1], _lib.RN_RUN_SWEEP, it)
-            if dist is None:
-                continue
-            pc["ev"][p].record()
-            with torch.cuda.stream(side):
-                side.wait_event(pc["ev"][p])
-                self._mark("exchange", True)
-                dist.all_reduce(bufs[p], op=dist.ReduceOp.SUM)
-                self._mark("exchange", False)
-        if dist is not None:
-            torch.cuda.current_stream(ctx.device).wait_stream(side)
-        if fixed:
-            # integer sums: the same bits as one scatter into one partial, whatever K
-            torch.sum(bufs, dim=0, out=plan["acc_part"])
-            bufs.zero_()
-            ctx.scene_run(plan["fast"], _lib.RN_RUN_COMBINE, it)
-        else:
-            torch.sum(bufs, dim=0, out=out)
-
     def _run_plan_path(self, plan, ctx, refs, dist, world, slot, captured=False):
         """One pass as phases of the C plan (include/raynet_hip.h, rn_scene_run): 1 + T calls
         for the K1 prefix and the T BP iterations, the exchange between them, then the depth
@@ -992,11 +854,7 @@ class RayNetForwardPass(ForwardPass):
                 plan["acc_b"].fill_(plan["prior"])
             else:
                 plan["acc_b"].zero_()
-        pieces = self._pieces(plan, ctx, len(refs)) if T > 1 else None
         for it in range(T):
-            if pieces is not None and it > 0:
-                self._sweep_in_pieces(plan, ctx, dist, pieces, it)
-                continue
             ctx.scene_run(fast, (_lib.RN_RUN_PREPARE if it == 0 else 0) | _lib.RN_RUN_SWEEP, it)
             self._exchange(plan, ctx, dist, world, it)
         final = plan["acc_b" if (T - 1) & 1 else "acc_a"]
@@ -1015,73 +873,39 @@ class RayNetForwardPass(ForwardPass):
                     ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, a)
                 plan["ev_ready"][a].record()
             self._emit_direct(plan, groups, slot)
-        elif dist is not None and plan.get("a2a") is not None:
-            # owner-only maps: ONE depth launch over all of this rank's rows, ONE collective
-            # that takes image k's rows of every rank to k's owner, ONE stitch launch there
-            a2a = plan["a2a"]
+        elif dist is not None:
+            # sharded rays, owner-only maps (_epilogue_buffers): ONE depth launch over all of
+            # this rank's rows, ONE all-gather of the ranks' rows, ONE stitch launch on an owner
+            rows = plan["rows"]
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, 0 | (V << 16))
             plan["ev_ready"][0].record()
             side = self._side_stream
             with torch.cuda.stream(side):
                 side.wait_event(plan["ev_ready"][0])
                 self._mark("gather", True)
-                if a2a["all_to_all"]:
-                    _all_to_all_rows(dist, a2a["recv"][:-1], plan["depth"], a2a["out_split"],
-                                     a2a["in_split"])
-                else:
-                    dist.all_gather_into_tensor(a2a["recv"][:-1], plan["depth"])
+                dist.all_gather_into_tensor(rows["recv"][:-1], plan["depth"])
                 self._mark("gather", False)
-                mine = a2a["mine"]
+                mine = rows["mine"]
                 if mine:
                     HW = plan["maps_dev"].shape[1]
                     host = plan["host"][slot].view(-1)
-                    ctx.stitch_rows(a2a["recv"], a2a["table"],
+                    ctx.stitch_rows(rows["recv"], rows["table"],
                                     host[mine[0] * HW:(mine[-1] + 1) * HW])
                 plan["ev_done"][0].record()
             for k in range(V):
                 plan["wait_ev"][k] = plan["ev_done"][0]
-        elif dist is not None and plan.get("rank_groups"):
-            # a rank of several: every group of images is ONE depth launch (all of them enqueued
-            # first: the GPU never waits for the host between them), then per group ONE
-            # all-gather of the ranks' row blocks and ONE rn_stitch_rows launch that puts them
-            # into pixel order and writes the pinned host maps across PCIe itself -- on the two
-            # side streams in turns, so that a group's exchange does not queue behind the
-            # previous group's PCIe transfer.  (Collectives are issued in the same order on
-            # every rank.)
-            groups = plan["rank_groups"]
-            npad = plan["npad"]
-            for a, b in groups:
-                if b - a > 1:
-                    ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, a | ((b - a) << 16))
-                else:
-                    ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, a)
-                plan["ev_ready"][a].record()
-            HW = plan["maps_dev"].shape[1]
-            host = plan["host"][slot].view(-1)
-            for i, (a, b) in enumerate(groups):
-                side = self._copy_stream if i & 1 else self._side_stream
-                with torch.cuda.stream(side):
-                    side.wait_event(plan["ev_ready"][a])
-                    g = plan["gathered_grp"][i]
-                    self._mark("gather", True)
-                    dist.all_gather_into_tensor(g[:-1], plan["depth"][a * npad:b * npad])
-                    self._mark("gather", False)
-                    ctx.stitch_rows(g, plan["stitch32_grp"][i], host[a * HW:b * HW])
-                    plan["ev_done"][a].record()
-                for k in range(a, b):
-                    plan["wait_ev"][k] = plan["ev_done"][a]
-        elif dist is None and V >= 3 and self.options.depth_head:
+        elif V >= 3 and self.options.depth_head:
             # one GPU: all images but the last decoded by ONE launch (no launch tails between
             # them), the last on its own -- long enough for the others' maps to leave under it.
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, 0 | ((V - 1) << 16))
             for j in range(V - 1):
-                self._emit_image(plan, j, per_image[refs[j]], dist, world, slot)
+                self._emit_image(plan, j, per_image[refs[j]], slot)
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, V - 1)
-            self._emit_image(plan, V - 1, per_image[refs[V - 1]], dist, world, slot)
+            self._emit_image(plan, V - 1, per_image[refs[V - 1]], slot)
         else:
             for k, r in enumerate(refs):
                 ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, k)
-                self._emit_image(plan, k, per_image[r], dist, world, slot)
+                self._emit_image(plan, k, per_image[r], slot)
         if captured:
             cur = torch.cuda.current_stream(ctx.device)
             cur.wait_stream(self._side_stream)
@@ -1126,9 +950,6 @@ class RayNetForwardPass(ForwardPass):
             return False
         if dist is not None and not (getattr(dist, "capturable", False) or _backend_of(dist) == "nccl"):
             return False
-        if dist is not None and plan.get("a2a") is not None and plan["a2a"]["all_to_all"] and \
-                not getattr(dist, "capturable", False):
-            return False              # (RCCL's all-to-all inside a capture: see _epilogue_buffers)
         return plan["passes"] >= 2 and ctx.scatter_settled()
 
     # -- the resident schedule ------------------------------------------------------------------
@@ -1205,18 +1026,10 @@ class RayNetForwardPass(ForwardPass):
             self._epilogue_buffers(plan, refs, H, W, dev, world, rank, dist is not None)
             V = len(refs)
             self._scatter_work_list(plan, ctx)
-            # which pinned set this pass writes.  "view" / "auto": the two sets in turns, so that a
-            # pass's maps outlive the next pass; "auto" looks, before it overwrites a set, whether
-            # the caller still holds a map (or a view of one) of the pass before last -- then the
-            # caller keeps that memory, the plan takes ONE new set and yields copies from now on.
-            if plan["copy_maps"]:
-                slot = 0
-            else:
-                slot = plan["slot"] ^ 1
-                if self.options.maps == "auto" and self._maps_held(plan, slot):
-                    h, roots = self._host_set(V, H * W, dev.type == "cuda")
-                    plan["host"], plan["host_root"] = [h, None], [roots, None]
-                    plan["copy_maps"], plan["graphs"], slot = True, {}, 0
+            # which pinned set this pass writes: "copy" hands out fresh arrays (one set);
+            # "view" hands out views of the two sets in turns, so that a pass's maps outlive
+            # the next pass
+            slot = 0 if plan["copy_maps"] else plan["slot"] ^ 1
             plan["slot"] = slot
             # (a pass whose launches or exchanges are bracketed by events runs eagerly)
             eager = self.trace is not None or getattr(ctx, "prof_active", False) or \
@@ -1259,7 +1072,7 @@ class RayNetForwardPass(ForwardPass):
             for k, r in enumerate(refs):
                 self.ref_idx = r
                 if owners is not None and owners[k] != rank:
-                    yield None             # another rank assembles this image (PathOptions.gather)
+                    yield None             # another rank assembles this image (map_owner)
                     continue
                 ev = plan["wait_ev"][k]
                 if spin:
@@ -1361,37 +1174,22 @@ class RayNetForwardPass(ForwardPass):
             # shipped quirk every iteration does (memmap reopened with mode="w+", Q1)
             first = it == 0 or self.reference_quirks
             plan["dirty"] = True
-            # PathOptions.exchange_pieces = K > 1 (a process group, all columns resident): the
-            # images in K groups, each scattering into its own partial, which is all-reduced as
-            # soon as the group is done; the accumulator is the sum of the reduced partials
-            K = min(int(self.options.exchange_pieces), V) if (collective and one_group and groups) else 1
-            if K > 1 and "granular_parts" not in plan:
-                plan["granular_parts"] = [torch.zeros_like(acc_part) for _ in range(K)]
             for group in groups:
                 if not one_group:
                     prepare(group)
                 n_g = len(group) * npad
                 g_row0 = group[0] * npad
                 B_g = self.rays_batch // 256 * 256 if self.rays_batch and self.rays_batch >= 256 else n_g
-                cuts = [V * p // K * npad for p in range(K + 1)] if K > 1 else [0, n_g]
-                for p in range(len(cuts) - 1):
-                    part = plan["granular_parts"][p] if K > 1 else acc_part
-                    for i in range(cuts[p], cuts[p + 1], B_g):
-                        j = min(i + B_g, cuts[p + 1])
-                        sweep(Sr_g[i:j], vox_g[i:j], rvc_all[g_row0 + i:g_row0 + j], acc_in,
-                              msgs_all[g_row0 + i:g_row0 + j], part,
-                              first_sweep=first, patch_rows=patch_rows,
-                              uniform_acc=it == 0)      # iteration 0: the prior everywhere
-                    if K > 1:
-                        dist.all_reduce(part, op=dist.ReduceOp.SUM)
+                for i in range(0, n_g, B_g):
+                    j = min(i + B_g, n_g)
+                    sweep(Sr_g[i:j], vox_g[i:j], rvc_all[g_row0 + i:g_row0 + j], acc_in,
+                          msgs_all[g_row0 + i:g_row0 + j], acc_part,
+                          first_sweep=first, patch_rows=patch_rows,
+                          uniform_acc=it == 0)      # iteration 0: the prior everywhere
             # swap + prior refill of forward_pass.py:676-678; across ranks the partial sums are
             # merged first (integer sums in the deterministic mode: the same bits whatever the
             # ring order) and the prior is added once, after the sum
-            if K > 1:
-                torch.sum(torch.stack(plan["granular_parts"]), dim=0, out=acc_part)
-                for part in plan["granular_parts"]:
-                    part.zero_()
-            elif collective:
+            if collective:
                 dist.all_reduce(acc_part, op=dist.ReduceOp.SUM)
             combine(acc_part, prior, acc_next)
             # (the prior buffer never becomes a destination)
@@ -1495,14 +1293,13 @@ class RayNetForwardPass(ForwardPass):
             st = per_image[r]
             self.messages.put(r, st["msgs"], st["rvc"])
             self.voxel_count[r] = st["rvc"]
-        # with a process group, image k's map is handed out by ONE rank (PathOptions.gather; this
+        # with a process group, image k's map is handed out by ONE rank (map_owner; this
         # launch-by-launch path still moves every map to every rank: it is the fallback)
-        mode = self.options.gather if collective else "all"
         for k, (r, host, done) in enumerate(pending):
             if done is not None:
                 done.synchronize()
             self.ref_idx = r
-            if mode != "all" and map_owner(k, V, world, mode) != rank:
+            if collective and map_owner(k, V, world) != rank:
                 yield None
                 continue
             yield host.numpy().reshape(W, H).T

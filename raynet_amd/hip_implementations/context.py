@@ -54,6 +54,9 @@ def _chk(t, dtype, min_numel=0, name="tensor", optional=False, align=4):
     return t
 
 
+SCATTER_ITEM_TILES = 1 << 19      # tiles an int32 item `tile << 12 | ...` can name
+
+
 def scatter_work_list(rvc, M, level=0, target_items=2048):
     """int32 items `tile << 12 | first chunk << 6 | chunks` for the LDS-box scatter at tile
     `level` (0: 128 rays x 32 steps, 1: 256 x 16) from the rays' voxel counts [rows]: a tile's
@@ -69,7 +72,9 @@ def scatter_work_list(rvc, M, level=0, target_items=2048):
         c = torch.cat([c, torch.zeros((pad,), dtype=c.dtype, device=c.device)])
     nch = (c.view(-1, tile).max(1).values + steps - 1) // steps          # live chunks per tile
     total = int(nch.sum().item())
-    if total == 0:
+    if total == 0 or len(nch) > SCATTER_ITEM_TILES:
+        # (an item's tile field has 19 bits: a larger plan keeps the scatter's tiles x split launch;
+        # rn_scene_bind_scatter_items refuses such rows as well)
         return None
     U = int(min(63, max(1, -(-total // int(target_items)))))
     per_tile = (nch + U - 1) // U                                        # items per tile
@@ -567,34 +572,6 @@ class HipContext(object):
             pl.depth_image, pl.depth_image_stride = depth_image.data_ptr(), int(depth_image.shape[1])
         pl._keepalive = (ray_idxs, feature_table, cameras, vox, rvc, Sr, msgs, acc0, acc1, depth,
                          acc_fixed, order, seg, depth_image)
-        pl._ref = ctypes.byref(pl)
-        return pl
-
-    def scene_plan_piece(self, plan, first_image, n_images, acc_out, parity, acc_fixed=None):
-        """A copy of `plan` restricted to the images [first_image, first_image + n_images) whose
-        SWEEP phase of an iteration with `iteration & 1 == parity` scatters into `acc_out`
-        (rn_acc_size floats) instead of the plan's own accumulator -- and reads the plan's other
-        accumulator as it is (PathOptions.exchange_pieces).  acc_fixed: the piece's own int64
-        partial in the deterministic mode."""
-        pl = _lib.ScenePlan()
-        ctypes.pointer(pl)[0] = plan          # field-by-field copy of the struct
-        M, rows0 = self.M, int(first_image) * int(plan.rows_per_image)
-        cam_stride = 12 * self.N + 16
-        assert 0 <= first_image and n_images >= 1 and first_image + n_images <= plan.n_images
-        _chk(acc_out, torch.float32, self.acc_size(), "acc_out", align=16)
-        _chk(acc_fixed, torch.int64, self.acc_size(), "acc_fixed", optional=True, align=16)
-        pl.n_images = int(n_images)
-        pl.features_views = plan.features_views + 8 * first_image * self.N
-        pl.cameras = plan.cameras + 4 * first_image * cam_stride
-        pl.vox, pl.Sr, pl.msgs = (getattr(plan, f) + 4 * rows0 * M for f in ("vox", "Sr", "msgs"))
-        pl.rvc, pl.depth = plan.rvc + 4 * rows0, plan.depth + 4 * rows0
-        if plan.ray_segments:
-            pl.ray_segments = plan.ray_segments + 4 * rows0 * 8
-        pl.depth_image = None
-        pl.acc[parity] = acc_out.data_ptr()
-        pl.acc[1 - parity] = plan.acc[1 - parity]
-        pl.acc_fixed = acc_fixed.data_ptr() if acc_fixed is not None else None
-        pl._keepalive = (plan, acc_out, acc_fixed)
         pl._ref = ctypes.byref(pl)
         return pl
 

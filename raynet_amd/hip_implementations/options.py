@@ -46,9 +46,6 @@ class PathOptions:
     plan_path: bool = True            # one C call per phase of a pass (rn_scene_run) when the pass qualifies
     depth_head: bool = True           # one GPU: all images but the last decoded by one launch
     direct_maps: bool = True          # no process group: the depth sweeps write pixel-order maps
-    rank_group: int = 2               # with a process group: images per depth launch + all-gather +
-    #                                   stitch of a rank (the last group takes the rest); 0: the
-    #                                   per-image exchange through index_select and a copy
     spin_wait: bool = False           # poll the maps' events instead of blocking on them
     capture: str = "auto"             # the plan path's whole step (phases, exchanges, epilogue) as ONE
     #                                   captured HIP graph per plan, replayed per pass -- no interpreter and
@@ -57,10 +54,10 @@ class PathOptions:
     #                                   ahead of a 6.7 ms step anyway; a 1 ms step of eight ranks does not
     #                                   wait for it: -5 %).  RCCL's collectives are captured with the
     #                                   launches; other transports keep the eager schedule
-    maps: str = "auto"                # what a pass yields: "view" = views of the plan's pinned host maps
-    #                                   (valid until the second-next pass), "copy" = fresh arrays like the
-    #                                   reference's .get() (forward_pass.py:739-744), "auto" = views until
-    #                                   a caller is seen to keep one across passes, copies from then on
+    maps: str = "copy"                # what a pass yields: "copy" = fresh arrays like the reference's
+    #                                   .get() (forward_pass.py:739-744); "view" = views of the plan's two
+    #                                   pinned host sets, used in turns -- valid until the second-next pass
+    #                                   over the same plan (zero-copy, for callers that consume a map at once)
     # ---- memory ---------------------------------------------------------------------------
     resident_gb: float = 0.0          # HBM budget of the resident schedule; 0: 90 % of what is free
     # ---- multi-GPU ------------------------------------------------------------------------
@@ -70,16 +67,6 @@ class PathOptions:
     #                                       count; None: derived from the shape (shard_alpha_for)
     exchange: str = "allreduce"       # deterministic mode only: "reduce_scatter" = int64 reduce-scatter,
     #                                   combine on the rank's slab, float all-gather (3/4 of the bytes)
-    gather: str = "owner"             # with a process group, who assembles image k's map: "owner" = ONE
-    #                                   rank (k * world // images; the others yield None for it), "rank0",
-    #                                   or "all" = every rank every map (all-gather + stitch + host copy
-    #                                   on all of them: round 3's epilogue)
-    rows_exchange: str = "all_gather"  # how the depth rows reach the maps' owners: one all-gather (every
-    #                                   rank receives all rows, the owners use theirs; captured with the
-    #                                   step) or "all_to_all" (only what an owner needs travels; eager)
-    exchange_pieces: int = 1          # a BP iteration's rows in this many image groups, each group's
-    #                                   partial sums all-reduced on a side stream under the next group's
-    #                                   kernels (K x the bytes on the wire)
     # ---- the context's own options (rn_options in include/raynet_hip.h) ---------------------
     scatter_mode: int = -1            # -1 by row layout, 0 slab scatter, 2 LDS-box scatter
     box_level: int = 0                # tile shape the adaptive box scatter starts from
@@ -99,13 +86,9 @@ class PathOptions:
         "RAYNET_PLAN_PATH": ("plan_path", _flag),
         "RAYNET_DEPTH_HEAD": ("depth_head", _flag),
         "RAYNET_DIRECT_MAPS": ("direct_maps", _flag),
-        "RAYNET_RANK_GROUP": ("rank_group", int),
         "RAYNET_SPIN_WAIT": ("spin_wait", _flag),
         "RAYNET_CAPTURE": ("capture", lambda t: {"0": "off", "1": "on"}.get(str(t).strip(), str(t).strip())),
         "RAYNET_MAPS": ("maps", str),
-        "RAYNET_GATHER": ("gather", str),
-        "RAYNET_EXCHANGE_PIECES": ("exchange_pieces", int),
-        "RAYNET_ROWS_EXCHANGE": ("rows_exchange", str),
         "RAYNET_RESIDENT_GB": ("resident_gb", float),
         "RAYNET_DETERMINISTIC": ("deterministic", _flag),
         "RAYNET_SHARD": ("shard", str),
@@ -129,12 +112,8 @@ class PathOptions:
         assert self.exchange in ("allreduce", "reduce_scatter"), self.exchange
         assert self.scatter_mode in (-1, 0, 2) and self.box_level in (0, 1, 2)
         assert self.overlap in (0, 1, 2)
-        assert self.rank_group >= 0
-        assert self.maps in ("auto", "copy", "view"), self.maps
+        assert self.maps in ("copy", "view"), self.maps
         assert self.capture in ("auto", "on", "off"), self.capture
-        assert self.gather in ("owner", "rank0", "all"), self.gather
-        assert self.exchange_pieces >= 1
-        assert self.rows_exchange in ("all_gather", "all_to_all"), self.rows_exchange
 
     @classmethod
     def from_env(cls, environ=None, **overrides):

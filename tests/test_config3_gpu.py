@@ -1,0 +1,193 @@
+"""BASELINE.json configs[2] and the 8-way half of configs[3] at their FULL sizes through the
+N-rank path, on one GPU: eight processes (gloo: RCCL wants one GPU per rank) share cuda:0, each
+runs the real HIP kernels on its work-balanced shard of every reference image, the partial sums
+meet in ONE all-reduce per BP iteration, image k's map is assembled by its owner.
+
+What is held: in the fixed-point mode the accumulator and every owner-assembled
+map are BIT-IDENTICAL to the one-rank run; in the float mode the accumulator agrees within the
+re-association tolerance (16 ulp of the largest accumulator: 1e-3 where |acc| reaches 789) and
+every pixel that differs is an arg-max near-tie; every rank's work (voxel visits + the plane
+sweep's per-ray constant) within +-10 % of the mean.  The sweep a shard must reproduce is /root/reference/raynet/forward_pass.py:593-664.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = {
+    # BASELINE.json configs[1] / [2]
+    "config2": dict(H=480, W=640, V=5, D=64, M=384, grid=(128, 128, 128), nb=4),
+    # BASELINE.json configs[3]
+    "config4": dict(H=480, W=640, V=9, D=128, M=768, grid=(256, 256, 256), nb=8),
+}
+
+
+def _scene(size):
+    from raynet_amd.common.generation_parameters import GenerationParameters
+    from raynet_amd.synthetic import make_synthetic_scene
+    c = SIZES[size]
+    scene, bank = make_synthetic_scene(H=c["H"], W=c["W"], n_views=c["V"], focal=1.5 * c["H"], seed=1234)
+    gp = GenerationParameters(depth_planes=c["D"], neighbors=c["nb"],
+                              grid_shape=np.array(c["grid"], np.int32),
+                              max_number_of_marched_voxels=c["M"], padding=11, gamma_mrf=0.05)
+    return c, scene, bank, gp
+
+
+def _rank_main(rank, world, port, out_dir, size, deterministic):
+    import sys
+    import torch
+    import torch.distributed as dist
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    from raynet_amd.forward_pass import get_forward_pass_factory, map_owner
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+    c, scene, bank, gp = _scene(size)
+    V, H, W = c["V"], c["H"], c["W"]
+    fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0,
+                                            deterministic=deterministic)
+    maps = list(fp.forward_pass(scene, (0, V, 1)))
+    assert fp._plan["fast"] is not None                 # the plan path: what bench.py --gpus N runs
+    owned = [k for k in range(V) if map_owner(k, V, world) == rank]
+    assert [m is not None for m in maps] == [k in owned for k in range(V)]
+    acc = fp.accumulator.cpu().numpy()
+    out = dict(owned=np.array(owned, np.int64), balance=np.array(fp.shard_balance),
+               alpha=np.float64(fp.shard_alpha),
+               rows=np.array([len(fp.ray_index[r]) for r in range(V)]))
+    for k in owned:
+        out["depth_%d" % k] = maps[k]
+    if rank == 0:
+        out["acc"] = acc
+    else:       # every rank holds the same merged accumulator: a checksum is enough to say so
+        out["acc_sum"] = np.array([np.float64(acc.astype(np.float64).sum()), float(acc.max()), float(acc.min())])
+    np.savez(os.path.join(out_dir, "%s_%s_r%d.npz" % (size, "d" if deterministic else "f", rank)), **out)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(tmp_path, size, deterministic, world=8):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, str(tmp_path), size, deterministic))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    ranks = [np.load(os.path.join(str(tmp_path), "%s_%s_r%d.npz" % (size, "d" if deterministic else "f", q)))
+             for q in range(world)]
+    V = SIZES[size]["V"]
+    depth = [None] * V
+    for rq in ranks:
+        for k in rq["owned"]:
+            assert depth[int(k)] is None             # each map from exactly one rank
+            depth[int(k)] = rq["depth_%d" % int(k)]
+    assert all(d is not None for d in depth)
+    acc = ranks[0]["acc"]
+    ref = np.array([np.float64(acc.astype(np.float64).sum()), float(acc.max()), float(acc.min())])
+    for rq in ranks[1:]:
+        assert np.array_equal(rq["acc_sum"], ref)
+        assert np.array_equal(rq["balance"], ranks[0]["balance"])
+    return acc, np.stack(depth), ranks
+
+
+def _balance_ok(ranks, size, world=8):
+    c = SIZES[size]
+    rows = np.stack([rq["rows"] for rq in ranks])
+    assert np.all(rows.sum(0) == c["H"] * c["W"])                  # every ray owned once
+    visits = ranks[0]["balance"].astype(np.float64).sum(0)         # [world]
+    assert len(visits) == world
+    # what the cuts equalise is a rank's WORK: its traversed voxels plus, for every ray, the plane
+    # sweep's cost in units of a voxel visit (alpha x the mean count: options.shard_alpha_for --
+    # 0.37 at config 2, 0.68 at config 4, where the border ranks' many short rays weigh more)
+    alpha = float(ranks[0]["alpha"])
+    mean_count = visits.sum() / (c["V"] * c["H"] * c["W"])
+    work = visits + alpha * mean_count * rows.sum(1)
+    assert np.all(np.abs(work / work.mean() - 1) <= 0.10), (work / work.mean(), visits / visits.mean())
+    assert np.all(np.abs(visits / visits.mean() - 1) <= 0.20), visits / visits.mean()
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no CPU fallback exists)"
+    from raynet_amd import _lib
+    _lib.build()
+    return torch
+
+
+def test_config3_full_size_eight_ranks_over_gloo(torch, oracle_mod, tmp_path):
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    c, scene, bank, gp = _scene("config2")
+    V, H, W, M = c["V"], c["H"], c["W"], c["M"]
+    one = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0, deterministic=True)
+    depth_1 = np.stack(list(one.forward_pass(scene, (0, V, 1))))
+    acc_1 = one.accumulator.cpu().numpy()
+
+    # fixed point: eight ranks give the one-rank bits
+    acc_8, depth_8, ranks = _run_ranks(tmp_path, "config2", True)
+    assert np.array_equal(acc_8, acc_1)
+    assert np.array_equal(depth_8, depth_1)
+    _balance_ok(ranks, "config2")
+
+    # float sums: the stated tolerance, and every differing pixel an arg-max near-tie
+    acc_f, depth_f, _ = _run_ranks(tmp_path, "config2", False)
+    # (float sums of a few hundred messages per voxel in another order -- eight partial sums, the
+    # all-reduce's tree -- against the exact integer sum: a few ulp of the largest accumulator,
+    # 6e-5 at |acc| = 789; observed 7.5e-4)
+    assert np.abs(acc_f - acc_1).max() <= 16 * np.spacing(np.abs(acc_1).max())
+    o = oracle_mod.Oracle(M=M, D=c["D"], N=c["nb"] + 1, F=32, H=H, W=W, padding=11, bbox=scene.bbox.ravel(),
+                          grid_shape=c["grid"], threads=oracle_mod.Oracle.max_threads())
+    vg = oracle_mod.voxel_grid_centers(scene.bbox.ravel(), c["grid"])
+    differing = 0
+    for r in range(V):
+        d = np.abs(depth_f[r] - depth_1[r]).T.ravel()            # ray index = x * H + y
+        bad = np.where(d > 1e-4)[0]
+        differing += len(bad)
+        if not len(bad):
+            continue
+        views = scene.view_indices_with_neighbors(r, c["nb"])
+        f = bank.stacked(views).cpu().numpy()
+        P = np.array([scene.get_image(v).camera.P for v in views], np.float32)
+        Pi = scene.get_image(r).camera.P_pinv.astype(np.float32)
+        cc = scene.get_image(r).camera.center.ravel().astype(np.float32)
+        rows = {int(q): k for k, q in enumerate(one.ray_index[r].cpu().numpy())}
+        for idx in bad:
+            ridx = np.array([idx], np.int32)
+            rvi, rvc, Sv = o.fused_bp(ridx, f, P, Pi, cc, vg, o.prior(0.05), np.zeros((1, M), np.float32),
+                                      o.prior(0.05))
+            m = one.messages[r][rows[int(idx)]].cpu().numpy()[None]
+            S_new = o.depth_distribution(Sv, rvi, rvc, acc_1, m)
+            top = np.sort(S_new[0])[::-1]
+            assert top[0] - top[1] <= 5e-5, (r, int(idx), top[:2])
+    assert differing <= 16, differing
+
+
+def test_config4_eight_ranks_over_gloo(torch, tmp_path):
+    """The 8-way split of BASELINE.json configs[3] (9 views x 640x480 rays, 128 planes, 256^3,
+    M = 768), all nine reference images: fixed-point bits of the one-rank run, shard balance."""
+    from raynet_amd.forward_pass import get_forward_pass_factory
+    c, scene, bank, gp = _scene("config4")
+    V, H, W = c["V"], c["H"], c["W"]
+    one = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0, deterministic=True)
+    depth_1 = np.stack(list(one.forward_pass(scene, (0, V, 1))))
+    acc_1 = one.accumulator.cpu().numpy()
+    del one
+    torch.cuda.empty_cache()
+    acc_8, depth_8, ranks = _run_ranks(tmp_path, "config4", True)
+    assert np.array_equal(acc_8, acc_1)
+    assert np.array_equal(depth_8, depth_1)
+    _balance_ok(ranks, "config4")

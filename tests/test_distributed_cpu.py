@@ -20,7 +20,7 @@ from conftest import REPO
 H, W, D, M, GRID, VIEWS = 12, 16, 8, 48, (16, 16, 16), 3
 
 
-def _run(rank, world, port, out_dir, filtered=False, gather="owner", pieces=1):
+def _run(rank, world, port, out_dir, filtered=False):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from host_backend import OracleBackend
@@ -41,23 +41,19 @@ def _run(rank, world, port, out_dir, filtered=False, gather="owner", pieces=1):
         masks = [(rng.random((H, W)) > 0.35).astype(np.float32) for _ in range(VIEWS)]
         type(scene).get_depth_map = lambda self, i: masks[i]
     from raynet_amd.forward_pass import map_owner
-    from raynet_amd.hip_implementations.options import PathOptions
     fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 50,
                                             filter_out_rays=filtered,
-                                            backend_factory=OracleBackend,
-                                            options=PathOptions.from_env(gather=gather,
-                                                                         exchange_pieces=pieces))
+                                            backend_factory=OracleBackend)
     depths = list(fp.forward_pass(scene, (0, VIEWS, 1)))
-    # with a process group image k's map is handed out by ONE rank (PathOptions.gather, the
-    # reference needs it once: forward_pass.py:739-744); the others yield None for it
-    owned = np.array([world == 1 or gather == "all" or map_owner(k, VIEWS, world, gather) == rank
-                      for k in range(VIEWS)])
+    # with a process group image k's map is handed out by ONE rank (map_owner; the reference
+    # needs it once: forward_pass.py:739-744); the others yield None for it
+    owned = np.array([world == 1 or map_owner(k, VIEWS, world) == rank for k in range(VIEWS)])
     assert [d is not None for d in depths] == owned.tolist()
     if filtered:
         for d, m in zip(depths, masks):
             assert d is None or ((d[m == 0] == 0).all() and (d[m != 0] > 0).all())
     depths = [d if d is not None else np.zeros((H, W), np.float32) for d in depths]
-    tag = ("f" if filtered else "") + ("p%d" % pieces if pieces > 1 else "")
+    tag = "f" if filtered else ""
     rows = np.array([len(fp.ray_index[r]) for r in range(VIEWS)])
     np.savez(os.path.join(out_dir, "%sw%d_r%d.npz" % (tag, world, rank)), depth=np.stack(depths),
              owned=owned,
@@ -75,36 +71,31 @@ def _free_port():
     return p
 
 
-def _merged(ranks, gather):
-    """The maps the ranks handed out, put together: every image by exactly one rank (its owner),
-    or -- gather="all" -- by every rank, all of them the same."""
+def _merged(ranks):
+    """The maps the ranks handed out, put together: every image by exactly one rank, its owner."""
     owned = np.stack([rq["owned"] for rq in ranks])
-    assert np.all(owned.sum(0) == (len(ranks) if gather == "all" else 1)), owned
+    assert np.all(owned.sum(0) == 1), owned
     merged = np.zeros_like(ranks[0]["depth"])
-    for q, rq in enumerate(ranks):
+    for rq in ranks:
         for k in np.where(rq["owned"])[0]:
-            if gather == "all" and q > 0:
-                assert np.array_equal(rq["depth"][k], merged[k])
             merged[k] = rq["depth"][k]
     return merged
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,gather", [(2, "owner"), (4, "owner"), (2, "all"), (2, "rank0")])
-def test_multi_rank_forward_pass_matches_single_rank(tmp_path, world, gather):
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_forward_pass_matches_single_rank(tmp_path, world):
     out = str(tmp_path)
     _run(0, 1, 0, out)
-    mp.spawn(_run, args=(world, _free_port(), out, False, gather), nprocs=world, join=True)
+    mp.spawn(_run, args=(world, _free_port(), out, False), nprocs=world, join=True)
     one = np.load(os.path.join(out, "w1_r0.npz"))
     ranks = [np.load(os.path.join(out, "w%d_r%d.npz" % (world, q))) for q in range(world)]
     r0 = ranks[0]
     assert one["depth"].shape == (VIEWS, H, W)
-    # every rank holds the merged accumulator; every map is handed out (once, or by all)
+    # every rank holds the merged accumulator; every map is handed out once
     for rq in ranks[1:]:
         assert np.array_equal(r0["acc"], rq["acc"])
-    depth = _merged(ranks, gather)
-    if gather == "rank0":
-        assert r0["owned"].all()
+    depth = _merged(ranks)
     # prior counted once: the N-rank accumulator equals the 1-rank one up to fp32 re-association
     assert np.abs(one["acc"] - r0["acc"]).max() < 1e-4
     assert (np.abs(one["depth"] - depth) > 1e-4).mean() < 0.01
@@ -132,21 +123,4 @@ def test_two_rank_filtered_rays_and_patch_rows(tmp_path):
     r1 = np.load(os.path.join(out, "fw2_r1.npz"))
     assert np.array_equal(r0["acc"], r1["acc"])
     assert np.abs(one["acc"] - r0["acc"]).max() < 1e-4
-    assert (np.abs(one["depth"] - _merged([r0, r1], "owner")) > 1e-4).mean() < 0.01
-
-
-@pytest.mark.timeout(300)
-def test_exchange_in_pieces_equals_one_exchange(tmp_path):
-    """PathOptions.exchange_pieces = K: a BP iteration's images in K groups, every group's partial
-    sums all-reduced on their own (on hardware: on a side stream, under the next group's kernels)
-    and added up afterwards -- the accumulator and the maps of the one-exchange schedule (float
-    sums in another order: the usual tolerance; the real kernels' fixed-point mode: the same
-    bits, tests/test_forward_pass_gpu.py)."""
-    out = str(tmp_path)
-    mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
-    mp.spawn(_run, args=(2, _free_port(), out, False, "owner", 3), nprocs=2, join=True)
-    one = [np.load(os.path.join(out, "w2_r%d.npz" % q)) for q in range(2)]
-    pcs = [np.load(os.path.join(out, "p3w2_r%d.npz" % q)) for q in range(2)]
-    assert np.array_equal(pcs[0]["acc"], pcs[1]["acc"])
-    assert np.abs(one[0]["acc"] - pcs[0]["acc"]).max() < 1e-4
-    assert (np.abs(_merged(one, "owner") - _merged(pcs, "owner")) > 1e-4).mean() < 0.01
+    assert (np.abs(one["depth"] - _merged([r0, r1])) > 1e-4).mean() < 0.01

@@ -251,7 +251,7 @@ def test_config1_restrepo_cameras(torch, oracle_mod):
         assert _depth_close(depths[r], depth.reshape(W, H).T, S_new, W, H) <= 0.02
 
 
-def _rank_main(rank, world, port, out_dir, deterministic=False, gather="all"):
+def _rank_main(rank, world, port, out_dir, deterministic=False):
     import os
     import sys
     import torch
@@ -267,19 +267,12 @@ def _rank_main(rank, world, port, out_dir, deterministic=False, gather="all"):
     H, W = 48, 64
     scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
     from raynet_amd.forward_pass import map_owner
-    from raynet_amd.hip_implementations.options import PathOptions
     fp = get_forward_pass_factory("raynet")(bank, _gp(32, 192, (64, 64, 64)), "sample_in_bbox",
-                                            (H, W), 0, deterministic=deterministic,
-                                            options=PathOptions.from_env(
-                                                gather=gather.split("+")[0],
-                                                rows_exchange="all_to_all" if "+a2a" in gather
-                                                else "all_gather",
-                                                exchange_pieces=3 if "+pieces" in gather else 1))
-    gather = gather.split("+")[0]
+                                            (H, W), 0, deterministic=deterministic)
     depths = list(fp.forward_pass(scene, (0, 5, 1)))
-    if world > 1 and gather != "all":
+    if world > 1:
         # image k's map is handed out by its owner only; the others get None for it
-        owned = np.array([map_owner(k, 5, world, gather) == rank for k in range(5)])
+        owned = np.array([map_owner(k, 5, world) == rank for k in range(5)])
         assert [d is not None for d in depths] == owned.tolist()
         depths = [d if d is not None else np.zeros((H, W), np.float32) for d in depths]
     else:
@@ -302,10 +295,8 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world,gather", [(2, "owner"), (4, "owner+a2a"), (8, "owner"), (8, "all"),
-                                          (8, "owner+a2a"), (4, "rank0"), (2, "all"),
-                                          (4, "owner+pieces")])
-def test_sharded_ranks_on_real_kernels(torch, tmp_path, world, gather):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_ranks_on_real_kernels(torch, tmp_path, world):
     """2 / 4 / 8 ranks (gloo, all on cuda:0 -- RCCL needs one GPU per rank) run the real HIP
     kernels on their voxel-balanced ray shards; the merged accumulator and depth maps equal
     the single-rank run (prior counted once) and are the same on every rank."""
@@ -317,9 +308,8 @@ def test_sharded_ranks_on_real_kernels(torch, tmp_path, world, gather):
     procs[0].join(300)
     assert procs[0].exitcode == 0
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, out, False, gather))
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, out, False))
              for r in range(world)]
-    gather = gather.split("+")[0]
     for p in procs:
         p.start()
     for p in procs:
@@ -331,19 +321,13 @@ def test_sharded_ranks_on_real_kernels(torch, tmp_path, world, gather):
     for rq in ranks[1:]:
         assert np.array_equal(r0["acc"], rq["acc"])
         assert np.array_equal(r0["balance"], rq["balance"])
-    # every image's map is handed out: by every rank (gather="all", all of them equal), or by
-    # exactly one (the owner; PathOptions.gather)
+    # every image's map is handed out by exactly one rank, its owner (map_owner)
     owned = np.stack([rq["owned"] for rq in ranks])                         # [world, images]
-    assert np.all(owned.sum(0) == (world if gather == "all" else 1))
-    if gather == "rank0":
-        assert owned[0].all()
-    elif gather == "owner":
-        assert owned.sum(1).max() == -(-5 // world)                         # dealt out evenly
+    assert np.all(owned.sum(0) == 1)
+    assert owned.sum(1).max() == -(-5 // world)                             # dealt out evenly
     merged = np.zeros_like(one["depth"])
     for q, rq in enumerate(ranks):
         for k in np.where(rq["owned"])[0]:
-            if gather == "all" and q > 0:
-                assert np.array_equal(rq["depth"][k], merged[k])
             merged[k] = rq["depth"][k]
     assert np.abs(one["acc"] - r0["acc"]).max() < 5e-4
     assert (np.abs(one["depth"] - merged) > 1e-4).mean() < 0.01
@@ -415,7 +399,7 @@ def test_captured_step_replays_the_eager_pass(torch):
     cls = get_forward_pass_factory("raynet")
     for T in (3, 2):
         fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, bp_iterations=T,
-                 options=PathOptions(deterministic=True, capture="on"))
+                 options=PathOptions(deterministic=True, capture="on", maps="view" if T == 3 else "copy"))
         first = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
         acc = fp.accumulator.cpu().numpy()
         assert not fp.captured
@@ -429,7 +413,8 @@ def test_captured_step_replays_the_eager_pass(torch):
             assert np.array_equal(fp.accumulator.cpu().numpy(), acc)
             if sum(seen) >= 4:
                 break
-        assert seen[-1] and seen[-2] and len(fp._plan["graphs"]) == 2       # both host sets
+        # one graph per pinned host set: two sets of views in turns, one set behind fresh copies
+        assert seen[-1] and seen[-2] and len(fp._plan["graphs"]) == (2 if T == 3 else 1)
         # another iteration count on the same plan is another step: never the recorded one's replay
         fp.bp_iterations = T - 1
         fewer = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
@@ -452,44 +437,12 @@ def test_captured_step_replays_the_eager_pass(torch):
         assert not auto.captured and np.array_equal(d, first)
 
 
-def test_exchange_pieces_change_no_bit_in_fixed_point(torch):
-    """PathOptions.exchange_pieces = K: iterations >= 1 run group by group (K image groups, each
-    k_bp + scatter into its own partial accumulator, the partials summed afterwards -- with a
-    process group each is all-reduced under the next group's kernels).  Integer sums are
-    associative: in the fixed-point mode accumulator, messages and maps are the K = 1 bits for
-    every K; in float mode they agree to the usual re-association tolerance."""
-    from raynet_amd.forward_pass import get_forward_pass_factory
-    from raynet_amd.hip_implementations.options import PathOptions
-    from raynet_amd.synthetic import make_synthetic_scene
-    H, W = 48, 64
-    scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
-    gp = _gp(32, 192, (64, 64, 64))
-    cls = get_forward_pass_factory("raynet")
-    res = {}
-    for det in (True, False):
-        for K in (1, 2, 3, 5, 9):
-            fp = cls(bank, gp, "sample_in_bbox", (H, W), 0,
-                     options=PathOptions(deterministic=det, exchange_pieces=K))
-            d = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
-            assert ("pieces" in fp._plan) == (K > 1)
-            if K > 1:
-                assert fp._plan["pieces"]["K"] == min(K, 5)
-            res[det, K] = (d, fp.accumulator.cpu().numpy(), fp.messages[3].cpu().numpy())
-    for K in (2, 3, 5, 9):
-        for a, b in zip(res[True, 1], res[True, K]):
-            assert np.array_equal(a, b), K
-        assert np.abs(res[False, 1][1] - res[False, K][1]).max() <= 5e-4
-        assert np.abs(res[False, 1][2] - res[False, K][2]).max() <= 1e-4
-        assert (np.abs(res[False, 1][0] - res[False, K][0]) > 1e-4).mean() < 0.01
-
-
 def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
-    """PathOptions.maps.  "auto" (default): a pass yields views of plan-owned pinned memory
-    until a caller is seen to keep one across two later passes -- that caller keeps its
-    memory, the plan takes a new set and yields fresh arrays from then on (the reference hands
-    out fresh arrays from `.get()`, forward_pass.py:739-744).  "copy": fresh arrays always.
-    "view": the documented zero-copy lifetime (the second-next pass overwrites).  bp_iterations
-    is not part of the plan key, so passes with different T share one plan -- and differ."""
+    """PathOptions.maps.  "copy" (default): fresh arrays, like the reference's `.get()`
+    (forward_pass.py:739-744) -- whatever a caller keeps stays what it was.  "view": the
+    documented zero-copy lifetime (views of two pinned sets in turns: the second-next pass
+    overwrites).  bp_iterations is not part of the plan key, so passes with different T share
+    one plan -- and differ."""
     from raynet_amd.forward_pass import get_forward_pass_factory
     from raynet_amd.hip_implementations.options import PathOptions
     from raynet_amd.synthetic import make_synthetic_scene
@@ -503,38 +456,23 @@ def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
         return list(fp.forward_pass(scene, (0, 5, 1)))
 
     truth = {}
-    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True, maps="copy"))
+    assert PathOptions().maps == "copy"
+    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True))
     for T in (3, 1, 2):
         truth[T] = np.stack(run(fp, T))
     assert not np.array_equal(truth[3], truth[1])
-    a, b = run(fp, 3), run(fp, 1)
-    assert not any(np.shares_memory(x, y) for x in a for y in b)
-
-    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True))
-    a = run(fp, 3)
-    b = run(fp, 1)
-    assert not fp._plan["copy_maps"]
-    c = run(fp, 2)              # would land in a's pinned set: the plan sees `a` alive
-    assert fp._plan["copy_maps"]
+    a, b, c = run(fp, 3), run(fp, 1), run(fp, 2)
+    assert not any(np.shares_memory(x, y) for x in a for y in b + c)
     assert np.array_equal(np.stack(a), truth[3]) and np.array_equal(np.stack(b), truth[1])
-    assert np.array_equal(np.stack(c), truth[2])
-    d = run(fp, 3)
-    assert np.array_equal(np.stack(c), truth[2]) and np.array_equal(np.stack(d), truth[3])
-    # a caller that lets go of the maps (bench.py) never pays for a copy
-    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True))
-    for T in (3, 1, 2, 3):
-        got = np.stack(run(fp, T))          # (np.stack copies; the views die here)
-        assert np.array_equal(got, truth[T])
-    assert not fp._plan["copy_maps"]
-    # a slice of a map keeps the whole map alive, and counted
-    keep = run(fp, 1)[2][5:9, 7:11]
+    keep = run(fp, 1)[2][5:9, 7:11]                 # a slice of a map, kept across passes
     run(fp, 2)
     run(fp, 3)
-    assert fp._plan["copy_maps"] and np.array_equal(keep, truth[1][2][5:9, 7:11])
+    assert np.array_equal(keep, truth[1][2][5:9, 7:11])
 
     fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True, maps="view"))
     a = run(fp, 3)
     b = run(fp, 1)
+    assert np.array_equal(np.stack(a), truth[3])                   # outlives the next pass
     c = run(fp, 2)
     assert all(np.shares_memory(x, y) for x, y in zip(a, c))       # the documented lifetime
     assert np.array_equal(np.stack(a), truth[2]) and np.array_equal(np.stack(b), truth[1])
@@ -640,40 +578,36 @@ def test_ranks_without_rays_take_part_in_the_exchange(torch, monkeypatch):
             self.calls.append("all_gather")
             out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
 
-    H, W, world = 2, 3, 8
-    scene, bank = make_synthetic_scene(H=H, W=W, n_views=3, focal=1.5 * H)
+    world = 8
     empty = 0
-    for det in (False, True):
+    # (2 x 2 rays: the plan path; 2 x 3: H * W is no multiple of 4, rn_stitch_rows cannot put the
+    # owners' maps together with 16-byte stores and the pass runs launch by launch)
+    for (H, W), det in (((2, 2), False), ((2, 2), True), ((2, 3), True)):
+        scene, bank = make_synthetic_scene(H=H, W=W, n_views=3, focal=1.5 * H)
         for rank in range(world):
             stub = Stub(world)
             monkeypatch.setattr(F, "_dist", lambda s=stub, r=rank: (s, r, world))
             fp = F.get_forward_pass_factory("raynet")(
                 bank, _gp(8, 48, (16, 16, 16), neighbors=2), "sample_in_bbox", (H, W), 0,
-                options=PathOptions(shard="rays", deterministic=det, gather="all"))
+                options=PathOptions(shard="rays", deterministic=det))
             maps = list(fp.forward_pass(scene, (0, 3, 1)))
-            assert fp._plan["fast"] is not None
-            assert len(maps) == 3 and maps[0].shape == (H, W) and np.isfinite(np.stack(maps)).all()
+            assert (fp._plan["fast"] is not None) == ((H * W) % 4 == 0)
+            assert len(maps) == 3
+            for k in range(3):      # owner-only maps: image k from rank k * world // images only
+                assert (maps[k] is not None) == (F.map_owner(k, 3, world) == rank)
+                if maps[k] is not None:
+                    assert maps[k].shape == (H, W) and np.isfinite(maps[k]).all()
             calls = list(stub.calls)
-            if det:     # owner-only maps (the default): image k from rank k * world // images only
-                monkeypatch.setattr(F, "_dist", lambda s=Stub(world), r=rank: (s, r, world))
-                own = F.get_forward_pass_factory("raynet")(
-                    bank, _gp(8, 48, (16, 16, 16), neighbors=2), "sample_in_bbox", (H, W), 0,
-                    options=PathOptions(shard="rays", deterministic=det))
-                got = list(own.forward_pass(scene, (0, 3, 1)))
-                for k in range(3):
-                    assert (got[k] is not None) == (F.map_owner(k, 3, world, "owner") == rank)
-                    if got[k] is not None:
-                        assert np.array_equal(got[k], maps[k])
             n = len(fp.ray_index[0])
             empty += n == 0
-            # three exchanges of the sums (+ the agreement on the path), one all-gather per image
-            assert calls.count("all_gather") == 3 and calls.count("all_reduce") >= 3
-            if n == 0:
+            # three exchanges of the sums (+ the agreement on the path), ONE all-gather of the rows
+            assert calls.count("all_gather") == 1 and calls.count("all_reduce") >= 3
+            if n == 0 and fp._plan["fast"] is not None:
                 # nothing of an earlier pass survives in a rank's partial sums: all zero
                 acc = fp._acc_flat if not det else None
                 if acc is not None:
                     assert float(acc.abs().max()) == 0.0
-    assert empty >= 2           # 6 rays, 8 ranks
+    assert empty >= 2 * 4 + 2           # 4 / 4 / 6 rays, 8 ranks
 
 
 def test_unaligned_slices_are_accepted(torch):
@@ -730,11 +664,8 @@ def _nccl_single_main(port, out_dir):
     res = {}
     for tag, opt in (("f", PathOptions(capture="off")), ("d", PathOptions(deterministic=True, capture="off")),
                      ("rs", PathOptions(deterministic=True, exchange="reduce_scatter", capture="off")),
-                     ("all", PathOptions(deterministic=True, gather="all", capture="off")),
-                     ("a2a", PathOptions(deterministic=True, rows_exchange="all_to_all")),
                      ("cap", PathOptions(deterministic=True)),
-                     ("cappc", PathOptions(deterministic=True, exchange_pieces=2)),
-                     ("capall", PathOptions(deterministic=True, gather="all")),
+                     ("capf", PathOptions()),
                      ("g", PathOptions(plan_path=False))):
         fp = get_forward_pass_factory("raynet")(bank, _gp(32, 192, (64, 64, 64)), "sample_in_bbox",
                                                 (H, W), 0, options=opt)
@@ -743,7 +674,7 @@ def _nccl_single_main(port, out_dir):
         if tag == "rs":
             assert "slab_i" in fp._plan       # the reduce-scatter / all-gather pair did run
         if opt.plan_path:
-            assert (fp._plan["a2a"] is not None) == (opt.gather != "all")   # owner-only epilogue
+            assert fp._plan["rows"]["mine"] == [0, 1, 2, 3, 4]       # owner-only epilogue, one owner
         if tag.startswith("cap"):
             # the step as ONE captured graph, RCCL's collectives in it: once the scatter's
             # tile shape has settled every pass is a replay -- with the first pass's bits
@@ -753,15 +684,14 @@ def _nccl_single_main(port, out_dir):
                     break
             again = [m.copy() for m in fp.forward_pass(scene, (0, 5, 1))]
             assert fp.captured, "the step was never captured under RCCL"
-            assert all(np.array_equal(a, b) for a, b in zip(again, depths))
+            if opt.deterministic:
+                assert all(np.array_equal(a, b) for a, b in zip(again, depths))
         res[tag] = (np.stack(depths), fp.accumulator.cpu().numpy())
     np.savez(os.path.join(out_dir, "nccl.npz"), depth=res["f"][0], acc=res["f"][1],
              depth_fixed=res["d"][0], acc_fixed=res["d"][1], depth_rs=res["rs"][0],
              acc_rs=res["rs"][1], depth_granular=res["g"][0], acc_granular=res["g"][1],
-             depth_all=res["all"][0], acc_all=res["all"][1], depth_a2a=res["a2a"][0],
-             acc_a2a=res["a2a"][1], depth_cap=res["cap"][0],
-             acc_cap=res["cap"][1], depth_capall=res["capall"][0], acc_capall=res["capall"][1],
-             depth_cappc=res["cappc"][0], acc_cappc=res["cappc"][1])
+             depth_cap=res["cap"][0], acc_cap=res["cap"][1], depth_capf=res["capf"][0],
+             acc_capf=res["capf"][1])
     dist.destroy_process_group()
 
 
@@ -792,9 +722,10 @@ def test_rccl_code_path_in_a_one_rank_world(torch, tmp_path):
     assert np.array_equal(got["depth_fixed"], ref_d["depth"])
     assert np.array_equal(got["acc_rs"], ref_d["acc"])             # ... whatever the exchange
     assert np.array_equal(got["depth_rs"], ref_d["depth"])
-    for tag in ("all", "a2a", "cap", "capall", "cappc"):           # ... the epilogue / the pieces, eager or captured
-        assert np.array_equal(got["acc_" + tag], ref_d["acc"]), tag
-        assert np.array_equal(got["depth_" + tag], ref_d["depth"]), tag
+    assert np.array_equal(got["acc_cap"], ref_d["acc"])            # ... eager or captured
+    assert np.array_equal(got["depth_cap"], ref_d["depth"])
+    assert np.abs(got["acc_capf"] - ref["acc"]).max() < 5e-4        # the float step, captured
+    assert (np.abs(got["depth_capf"] - ref["depth"]) > 1e-4).mean() < 0.01
     assert np.abs(got["acc_granular"] - ref["acc"]).max() < 5e-4
     assert (np.abs(got["depth_granular"] - ref["depth"]) > 1e-4).mean() < 0.01
 
@@ -898,9 +829,11 @@ def test_deterministic_mode_is_bit_identical_across_runs_and_ranks(torch, tmp_pa
         p.join(300)
         assert p.exitcode == 0
     r0, r1 = np.load(out + "/dw2_r0.npz"), np.load(out + "/dw2_r1.npz")
-    assert np.array_equal(r0["acc"], r1["acc"]) and np.array_equal(r0["depth"], r1["depth"])
+    assert np.array_equal(r0["acc"], r1["acc"])
+    assert np.array_equal(r0["owned"] ^ r1["owned"], np.ones(5, bool))      # each map from ONE rank
+    depth = np.where(r0["owned"][:, None, None], r0["depth"], r1["depth"])
     assert np.array_equal(r0["acc"], runs[0][0])        # 2 ranks == 1 rank, bit for bit
-    assert np.array_equal(r0["depth"], runs[0][1])
+    assert np.array_equal(depth, runs[0][1])
     p = ctx.Process(target=_rank_main, args=(0, 1, 0, out, False))
     p.start()
     p.join(300)
@@ -938,15 +871,20 @@ def test_full_size_parity_with_the_oracle(torch, oracle_mod):
     """BASELINE.json config 2 in full (5 reference images of 480x640 rays, 64 planes, 128^3,
     M=384), per pixel: the HIP path against the C oracle run with the same schedule on the
     host's cores.  The oracle uses its robust message form: the literal
-    reference sequence overflows to +inf in a few voxels at this size, which is asserted too."""
+    reference sequence overflows to +inf in a few voxels at this size, which is asserted too.
+
+    Held for the FIRST pass of a fresh driver (what the reference's caller makes:
+    scripts/forward_pass.py:120-142), for the THIRD pass over the cached plan -- the steady state
+    bench.py times: scatter work list bound, the scatter's tile shape settled -- and for a
+    replay of the step as a captured HIP graph (`capture="on"`)."""
     from raynet_amd.forward_pass import get_forward_pass_factory
+    from raynet_amd.hip_implementations.options import PathOptions
     from raynet_amd.synthetic import make_synthetic_scene
     H, W, D, M, grid = 480, 640, 64, 384, (128, 128, 128)
     scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
     gp = _gp(D, M, grid)
-    fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0)
-    depth_hip = np.stack(list(fp.forward_pass(scene, (0, 5, 1))))
-    acc_hip = fp.accumulator.cpu().numpy()
+    fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 0,
+                                            options=PathOptions(capture="off"))
     o = oracle_mod.Oracle(M=M, D=D, N=5, F=32, H=H, W=W, padding=11, bbox=scene.bbox.ravel(),
                           grid_shape=grid, threads=oracle_mod.Oracle.max_threads())
     vg = oracle_mod.voxel_grid_centers(scene.bbox.ravel(), grid)
@@ -970,15 +908,13 @@ def test_full_size_parity_with_the_oracle(torch, oracle_mod):
             acc = out
         return acc, msgs
 
-    try:
-        oracle_mod.Oracle.set_robust_messages(True)
-        acc, msgs = run_oracle()
-        assert np.isfinite(acc).all()
-        assert np.abs(acc_hip - acc).max() < 2e-5 * np.abs(acc).max()
+    def check(what, depth_hip, acc_hip):
+        """this pass's maps, accumulator and (fp.messages) messages against the oracle's"""
+        assert np.abs(acc_hip - acc).max() < 2e-5 * np.abs(acc).max(), what
         inherited = differing = 0
         for r in range(5):
             f, P, Pi, c = cams[r]
-            rvi_o, rvc_o, S_new, depth = o.fused_depth(ridx, f, P, Pi, c, vg, acc, msgs[r])
+            depth, gap = depth_o[r], gap_o[r]
             d = np.abs(depth - depth_hip[r].T.ravel())
             # north star: depth maps within 1e-4 of the reference.  A pixel may differ only
             #  (a) at an arg-max near-tie of the reference (two best probabilities within 5e-5:
@@ -989,24 +925,51 @@ def test_full_size_parity_with_the_oracle(torch, oracle_mod):
             #      largest value) moves sigma(acc - msg) of a voxel whose sum nearly cancels.
             #      Proof per pixel: the ORACLE's own K2 arithmetic on this run's accumulator
             #      and this ray's messages picks the voxel the HIP path picked.
-            rows = {int(q): k for k, q in enumerate(fp.ray_index[r].cpu().numpy())}
+            rows = None
             for idx in np.where(d > 1e-4)[0]:
-                top = np.sort(S_new[idx])[::-1]
-                if top[0] - top[1] <= 5e-5:
+                if gap[idx] <= 5e-5:
                     continue
+                if rows is None:
+                    rows = {int(q): k for k, q in enumerate(fp.ray_index[r].cpu().numpy())}
                 m_hip = fp.messages[r][rows[int(idx)]].cpu().numpy()[None]
-                _, _, Sv_o = o.fused_bp(ridx[idx:idx + 1], f, P, Pi, c, vg, acc,
-                                        msgs[r][idx:idx + 1].copy(), o.prior(0.05))
-                again = o.depth_distribution(Sv_o, rvi_o[idx:idx + 1], rvc_o[idx:idx + 1],
-                                             acc_hip, m_hip)
-                d2 = o.depth_from_distribution(again, rvi_o[idx:idx + 1], vg, c)
-                assert abs(float(d2[0]) - float(depth_hip[r].T.ravel()[idx])) <= 1e-4, (r, idx)
+                rvi_1, rvc_1, Sv_o = o.fused_bp(ridx[idx:idx + 1], f, P, Pi, c, vg, acc,
+                                                msgs[r][idx:idx + 1].copy(), o.prior(0.05))
+                again = o.depth_distribution(Sv_o, rvi_1, rvc_1, acc_hip, m_hip)
+                d2 = o.depth_from_distribution(again, rvi_1, vg, c)
+                assert abs(float(d2[0]) - float(depth_hip[r].T.ravel()[idx])) <= 1e-4, (what, r, idx)
                 inherited += 1
             differing += int((d > 1e-4).sum())
-        # observed: 4 - 5 of the scene's 1,536,000 pixels (profiles/r02_k_fullsize_parity.json),
+        # observed: 2 - 5 of the scene's 1,536,000 pixels (profiles/r04_a_fullsize_parity.json),
         # each a near-tie or inherited as proven above
-        assert differing <= 8, differing
-        assert inherited <= 4, inherited
+        assert differing <= 8, (what, differing)
+        assert inherited <= 4, (what, inherited)
+
+    try:
+        oracle_mod.Oracle.set_robust_messages(True)
+        acc, msgs = run_oracle()
+        assert np.isfinite(acc).all()
+        depth_o, gap_o = {}, {}
+        for r in range(5):
+            f, P, Pi, c = cams[r]
+            _, _, S_new, depth_o[r] = o.fused_depth(ridx, f, P, Pi, c, vg, acc, msgs[r])
+            top = np.partition(S_new, M - 2, axis=1)[:, M - 2:]
+            gap_o[r] = np.abs(top[:, 1] - top[:, 0])
+            del S_new
+        first = np.stack(list(fp.forward_pass(scene, (0, 5, 1))))
+        check("first pass", first, fp.accumulator.cpu().numpy())
+        list(fp.forward_pass(scene, (0, 5, 1)))
+        third = np.stack(list(fp.forward_pass(scene, (0, 5, 1))))
+        assert fp._plan["passes"] == 3 and fp._plan.get("items") is not None       # work list bound
+        check("third pass", third, fp.accumulator.cpu().numpy())
+        fp.options = fp.options.replace(capture="on")       # (not part of a plan's key: same plan)
+        for _ in range(12):     # (the scatter's probe launches end within a few passes)
+            replay = np.stack(list(fp.forward_pass(scene, (0, 5, 1))))
+            if fp.captured:
+                break
+        assert fp.captured and fp._ctx.scatter_settled()
+        replay = np.stack(list(fp.forward_pass(scene, (0, 5, 1))))      # a replay, not the recording
+        assert fp.captured
+        check("captured replay", replay, fp.accumulator.cpu().numpy())
     finally:
         oracle_mod.Oracle.set_robust_messages(False)
 

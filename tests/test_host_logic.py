@@ -157,3 +157,20 @@ def test_scatter_work_list_covers_every_live_chunk_once():
             assert (np.diff(it & 63) <= 0).all()
             assert len(it) <= max(int(nch.sum()), 1)
     assert scatter_work_list(torch.ones(300, dtype=torch.int32), 96, 0) is None
+
+
+def test_scatter_work_list_stops_where_an_item_cannot_name_the_tile():
+    """An int32 item carries 19 bits of tile index: at the last representable plan the
+    highest tile still comes out right, one tile more and there is no list (the scatter then deals
+    tiles x chunks out itself; rn_scene_bind_scatter_items refuses such rows too)."""
+    import torch
+    from raynet_amd.hip_implementations.context import SCATTER_ITEM_TILES, scatter_work_list
+    tiles = SCATTER_ITEM_TILES
+    rvc = torch.zeros((tiles * 128,), dtype=torch.int32)
+    rvc[-1] = 40                                     # only the LAST tile is live: chunks 0 and 1
+    items = scatter_work_list(rvc, 96, 0, target_items=2048)
+    assert items is not None and items.dtype == torch.int32
+    got = sorted((int(v) >> 12, (int(v) >> 6) & 63, int(v) & 63) for v in items)
+    assert all(int(v) >= 0 for v in items) and got == [(tiles - 1, 0, 1), (tiles - 1, 1, 1)]
+    rvc = torch.cat([rvc, torch.full((128,), 40, dtype=torch.int32)])
+    assert scatter_work_list(rvc, 96, 0, target_items=2048) is None
