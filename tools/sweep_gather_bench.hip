@@ -1,0 +1,168 @@
+// sweep_gather_bench.hip -- the plane sweep's GATHERS alone, in different orders (round 5).
+//
+// Question: what would another decomposition of k_sweep_map buy on the
+// memory side, before building it?  Every kernel here performs exactly the feature-vector loads
+// of the plane sweep -- for every live ray, every neighbour view and every depth plane the 128-byte
+// vector the real sweep gathers (the offsets come from the library's own index arithmetic,
+// rn_selftest_feature_offsets) -- and nothing else: no projection, no pair products, no mapping.
+// What differs is WHO loads WHAT WHEN:
+//   k_ray_coop      the product's order: one wavefront per ray, 64 planes per chunk, 8 lanes fetch
+//                   one vector (16 B each), 8 planes per load round
+//   k_ray_lane      one wavefront per ray, lane = plane: a lane fetches its plane's whole vector
+//                   (8 x 16 B), no cooperation, no exchange of offsets
+//   k_tile_blocked  a workgroup owns a 16 x 16-pixel tile of rays (256 consecutive patch-ordered
+//                   rows) and walks the D planes in bands of PB planes: every wavefront takes
+//                   64 / PB rays x PB planes at a time, the tile finishes a band before any of its
+//                   wavefronts starts the next (the partial columns of the real kernel would wait
+//                   in LDS: D x 256 x 4 bytes, which is what limits it to one workgroup per CU --
+//                   emulated with `lds_bytes` of dynamic LDS)
+// Timed with events and counted with rocprofv3 --pmc by tools/sweep_gather_bench.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+constexpr int WAVE = 64, NXCD = 8;
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) char *gptr;
+typedef const __attribute__((address_space(1))) float4v *gptr4;
+
+struct Views {
+    const float *v[16];
+};
+
+__device__ __forceinline__ int xcd_block_rt(int b, int nblocks, int chunk) {
+    const int full = nblocks / (NXCD * chunk) * (NXCD * chunk);
+    if (b >= full) return b;
+    const int xcd = b % NXCD, pos = b / NXCD;
+    return ((pos / chunk) * NXCD + xcd) * chunk + pos % chunk;
+}
+
+__device__ __forceinline__ float sum4(float4v f) { return (f.x + f.y) + (f.z + f.w); }
+
+// one wavefront per ray, the product's cooperative rounds
+template <int NV>
+__global__ __launch_bounds__(256) void k_ray_coop(int n, int D, const int32_t *__restrict__ offs,
+                                                  const int32_t *__restrict__ live, Views fv,
+                                                  float *out, int chunk) {
+    const int lane = threadIdx.x & 63;
+    const int b = xcd_block_rt(blockIdx.x, (n + 3) / 4, chunk);
+    const int r = __builtin_amdgcn_readfirstlane(b * 4 + (int)(threadIdx.x >> 6));
+    if (r >= n || live[r] <= 1) return;
+    const int sub = lane >> 3, part = lane & 7;
+    float acc = 0.f;
+    for (int base = 0; base < D; base += WAVE) {
+        int ob[NV];
+#pragma unroll
+        for (int v = 1; v < NV; v++)
+            ob[v] = offs[((size_t)r * NV + v) * D + min(base + lane, D - 1)] << 7;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+#pragma unroll
+            for (int v = 1; v < NV; v++) {
+                const unsigned o = (unsigned)__shfl(ob[v], t * 8 + sub) + 16u * part;
+                acc += sum4(*(gptr4)((gptr)fv.v[v] + o));
+            }
+        }
+    }
+    out[(size_t)r * WAVE + lane] = acc;
+}
+
+// one wavefront per ray, lane = plane
+template <int NV>
+__global__ __launch_bounds__(256) void k_ray_lane(int n, int D, const int32_t *__restrict__ offs,
+                                                  const int32_t *__restrict__ live, Views fv,
+                                                  float *out, int chunk) {
+    const int lane = threadIdx.x & 63;
+    const int b = xcd_block_rt(blockIdx.x, (n + 3) / 4, chunk);
+    const int r = __builtin_amdgcn_readfirstlane(b * 4 + (int)(threadIdx.x >> 6));
+    if (r >= n || live[r] <= 1) return;
+    float acc = 0.f;
+    for (int base = 0; base < D; base += WAVE) {
+        if (base + lane < D) {
+#pragma unroll
+            for (int v = 1; v < NV; v++) {
+                const unsigned o = (unsigned)offs[((size_t)r * NV + v) * D + base + lane] << 7;
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc += sum4(*(gptr4)((gptr)fv.v[v] + o + 16u * q));
+            }
+        }
+    }
+    out[(size_t)r * WAVE + lane] = acc;
+}
+
+// a workgroup per 256-row tile, planes in bands of PB; WAVES wavefronts per workgroup
+template <int NV, int PB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_tile_blocked(int n, int D,
+                                                             const int32_t *__restrict__ offs,
+                                                             const int32_t *__restrict__ live,
+                                                             Views fv, float *out, int chunk) {
+    extern __shared__ float lds[];
+    constexpr int RPW = WAVE / PB;                       // rays per wavefront step
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ntiles = (n + 255) / 256;
+    const int tile = xcd_block_rt(blockIdx.x, ntiles, chunk);
+    const int row0 = tile * 256;
+    const int rsub = lane / PB, plane = lane % PB;
+    const int sub = lane >> 3, part = lane & 7;
+    float acc = 0.f;
+    if (threadIdx.x == 0) lds[0] = 0.f;                  // (the LDS is only there to cap occupancy)
+    for (int band = 0; band < D; band += PB) {
+        for (int it = w; it < 256 / RPW; it += WAVES) {
+            const int r = row0 + it * RPW + rsub;        // this lane's (ray, plane) sample
+            const bool ok = r < n && live[min(r, n - 1)] > 1;
+            int ob[NV];
+#pragma unroll
+            for (int v = 1; v < NV; v++)
+                ob[v] = ok ? (offs[((size_t)r * NV + v) * D + band + plane] << 7) : -1;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+#pragma unroll
+                for (int v = 1; v < NV; v++) {
+                    // (a dead ray's lanes fetch vector 0: no branch around a load)
+                    const int o = max(__shfl(ob[v], t * 8 + sub), 0);
+                    acc += sum4(*(gptr4)((gptr)fv.v[v] + (unsigned)o + 16u * part));
+                }
+            }
+        }
+        __syncthreads();                                 // the tile finishes a band together
+    }
+    out[(size_t)blockIdx.x * (WAVES * 64) + threadIdx.x] = acc;
+}
+}  // namespace
+
+template <int NV>
+static int launch(int variant, int n, int D, const int32_t *offs, const int32_t *live, Views fv,
+                  float *out, int chunk, int lds_bytes, hipStream_t st) {
+    const int ntiles = (n + 255) / 256;
+#define TILE(PB, WV)                                                                              \
+    {                                                                                             \
+        auto k = k_tile_blocked<NV, PB, WV>;                                                      \
+        if (lds_bytes > 65536)                                                                    \
+            (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      lds_bytes);                                                 \
+        hipLaunchKernelGGL(k, dim3(ntiles), dim3(WV * 64), lds_bytes, st, n, D, offs, live, fv,   \
+                           out, chunk);                                                           \
+    }
+    switch (variant) {
+        case 0: hipLaunchKernelGGL(k_ray_coop<NV>, dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
+        case 1: hipLaunchKernelGGL(k_ray_lane<NV>, dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
+        case 2: TILE(16, 16) break;
+        case 3: TILE(8, 16) break;
+        case 4: TILE(32, 16) break;
+        case 5: TILE(16, 8) break;
+        case 6: TILE(64, 16) break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int sgb_run(int variant, int n, int NV, int D, const int32_t *offs, const int32_t *live,
+                       const float *const *views_host, float *out, int chunk, int lds_bytes,
+                       void *stream) {
+    Views fv;
+    for (int v = 0; v < NV; v++) fv.v[v] = views_host[v];
+    hipStream_t st = (hipStream_t)stream;
+    if (NV == 5) return launch<5>(variant, n, D, offs, live, fv, out, chunk, lds_bytes, st);
+    if (NV == 9) return launch<9>(variant, n, D, offs, live, fv, out, chunk, lds_bytes, st);
+    return -1;
+}
