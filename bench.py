@@ -131,11 +131,13 @@ KERNEL_OF_FAMILY = {"sweep_map": "k_sweep_map", "bp": "k_bp", "scatter": "k_scat
                     "depth": "k_depth", "traverse": "k_traverse"}
 
 
-def live_pmc(config, family, budget_s=150.0):
-    """HBM-side traffic and VALU instructions of the dominant kernel, per launch, measured NOW:
-    three rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU: each counter set in
-    its own run, kernel-trace only, as MI355X_MICROARCH.md prescribes) of this very script with
-    --steps 1, spawned from here.  -> dict or None (no rocprofv3, a pass failed, out of time)."""
+def live_pmc(config, family, budget_s=180.0):
+    """HBM-side traffic, VALU instructions + the cycles the VALUs were busy with them, and the L2's
+    requests / misses of the dominant kernel, per launch, measured NOW: four rocprofv3 --pmc passes
+    (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU + SQ_ACTIVE_INST_VALU / TCC_REQ + TCC_MISS: each
+    counter set in its own run, kernel-trace only, as MI355X_MICROARCH.md prescribes) of this very
+    script with --steps 1, spawned from here.  -> dict or None (no rocprofv3, a pass failed, out
+    of time)."""
     import csv
     import glob
     import shutil
@@ -148,7 +150,8 @@ def live_pmc(config, family, budget_s=150.0):
     out = {}
     t_start = time.perf_counter()
     env = dict(os.environ, TMPDIR="/tmp")
-    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU"]):
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"],
+                     ["TCC_REQ_sum", "TCC_MISS_sum"]):
         left = budget_s - (time.perf_counter() - t_start)
         if left < 20:
             return None
@@ -162,6 +165,8 @@ def live_pmc(config, family, budget_s=150.0):
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL, timeout=min(left, 60.0))
             if r.returncode != 0:
+                if counters[0].startswith("TCC"):
+                    continue
                 return None
             tot, n = {}, {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -173,7 +178,9 @@ def live_pmc(config, family, budget_s=150.0):
                             n[c] = n.get(c, 0) + 1
             for c in counters:
                 if not n.get(c):
-                    return None
+                    if c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+                        return None
+                    continue            # (the newer, optional counters)
                 out[c] = tot[c] / n[c]
                 out["launches"] = n[c]
         except Exception:
@@ -446,7 +453,7 @@ def main():
         # HBM-side bytes per launch come from PMC counters, which need their own rocprofv3
         # passes (tools/pmc_passes.sh): the figure is read from the summary committed for
         # this configuration, never measured inside this run -- traffic_source says so
-        traffic = traffic_source = valu_insts = None
+        traffic = traffic_source = valu_insts = valu_active_quads = l2_req = l2_miss = None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
         live = None
         if world == 1 and args.pmc == "live":
@@ -458,8 +465,11 @@ def main():
             # 2 x FETCH_SIZE + WRITE_SIZE, KiB: the gfx950 correction of MI355X_MICROARCH.md (HBM)
             traffic = int((2 * live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024)
             valu_insts = live["SQ_INSTS_VALU"]
-            traffic_source = ("measured in this run: three rocprofv3 --pmc passes (FETCH_SIZE, "
-                              "WRITE_SIZE, SQ_INSTS_VALU; kernel-trace only) of `bench.py --steps 1` "
+            valu_active_quads = live.get("SQ_ACTIVE_INST_VALU")
+            l2_req, l2_miss = live.get("TCC_REQ_sum"), live.get("TCC_MISS_sum")
+            traffic_source = ("measured in this run: four rocprofv3 --pmc passes (FETCH_SIZE; "
+                              "WRITE_SIZE; SQ_INSTS_VALU + SQ_ACTIVE_INST_VALU; TCC_REQ + TCC_MISS; "
+                              "kernel-trace only) of `bench.py --steps 1` "
                               "spawned by this process, mean of %d launches, %.0f s" % (
                                   live["launches"], live["seconds"]))
         elif world == 1 and args.pmc != "off" and os.path.exists(tpath):   # N=1 launch sizes
@@ -478,6 +488,11 @@ def main():
         # its VALU instructions need to ISSUE (4 cycles each on one of 1024 SIMDs) -- counters
         # from the same separate PMC passes as `traffic`
         cyc, cyc_source = valu_cycles_per_inst(dominant, args.config)
+        if valu_insts and valu_active_quads:
+            # measured, not modelled: SQ_ACTIVE_INST_VALU counts the quad-cycles (4 shader cycles,
+            # MI355X_MICROARCH.md) the SIMDs spent on the kernel's VALU instructions as executed
+            cyc = 4.0 * valu_active_quads / valu_insts
+            cyc_source = "4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of this run's counter pass"
         valu_issue_ms = valu_insts * cyc / (N_SIMDS * VALU_CLOCK_HZ) * 1e3 if valu_insts else None
         strict = d["strict"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
         # what binds: the larger of (a) the time the kernel's memory-side bytes need -- the
@@ -497,6 +512,12 @@ def main():
                         valu_insts_per_launch=valu_insts,
                         valu_issue_ms=round(valu_issue_ms, 4) if valu_issue_ms else None,
                         valu_frac=round(valu_issue_ms / avg_ms, 4) if valu_issue_ms else None,
+                        # the gathers' side (profiles/r05_exp_sweep_gather_orders.txt: the sweep's
+                        # loads ALONE take ~85 % of the kernel's time): 128-byte line requests the
+                        # L1s sent to the L2, and how many of them missed there
+                        l2_requests_per_launch=int(l2_req) if l2_req else None,
+                        l2_misses_per_launch=int(l2_miss) if l2_miss else None,
+                        l2_to_l1_TBps=round(l2_req * 128 / (avg_ms * 1e-3) / 1e12, 2) if l2_req else None,
                         strict_algorithmic=dict(
                             what="SURVEY.md 8(d): the N feature maps once per reference image, no "
                                  "lists / columns / messages",

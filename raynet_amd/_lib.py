@@ -39,6 +39,14 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
             os.path.join(CSRC, "raynet_prepare.inl"), os.path.join(CSRC, "raynet_mrf.inl"),
             os.path.join(CSRC, "raynet_train.inl"), os.path.join(CSRC, "raynet_eval.inl"), HEADER]
     extra = list(extra_flags) + os.environ.get("RAYNET_HIPCC_EXTRA", "").split()
+    if out is None and os.environ.get("RAYNET_HIP_LIB"):
+        # RAYNET_HIP_LIB names ANOTHER build of the library (a variant somebody made on purpose):
+        # it is loaded as it is and never rebuilt with the default flags over its path -- an A/B
+        # run would then test the default build without saying so.  The in-tree path
+        # is the only implicit build target.
+        if not os.path.exists(LIB_PATH):
+            raise RaynetHipError("RAYNET_HIP_LIB=%s does not exist" % LIB_PATH)
+        return LIB_PATH
     target = out or LIB_PATH
     if extra and out is None:
         raise RaynetHipError("a variant build (%s) needs its own output path" % " ".join(extra))

@@ -364,6 +364,14 @@ __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureView
 #ifndef RN_SWEEP_V4
 #define RN_SWEEP_V4 1
 #endif
+// -DRN_SWEEP_STOP=n: k_sweep_map's wavefronts end after phase n -- 1 loads of segment / count / voxel
+// row, 12 projection, 2 gathers + pair sums, 3 softmax, 4 planes -> voxels, 45 clip + renormalise
+// (5: everything, the first BP iteration's messages included) -- so that SQ_INSTS_VALU of two
+// builds differs by one phase's EXECUTED instructions (tools/sweep_phase_budget.py).  Never set
+// in the shipped library (rn_version() names every -D of a variant build).
+#ifndef RN_SWEEP_STOP
+#define RN_SWEEP_STOP 0
+#endif
 #ifndef RN_SWEEP_UNROLL2_MAX_VIEWS
 #define RN_SWEEP_UNROLL2_MAX_VIEWS 6
 #endif
@@ -527,6 +535,15 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
                 offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, Pv, point, pad_shift);
             }
         }
+#if RN_SWEEP_STOP == 12      // (instruction budget: the projection alone, its offsets kept alive in LDS)
+        {
+            int keep = 0;
+#pragma unroll
+            for (int v = 0; v < NV; v++) keep ^= offb[v];
+            Sl[lane] = __builtin_bit_cast(float, keep);
+            continue;
+        }
+#endif
         // View 0 is the reference image itself: every plane of the ray projects onto the
         // ray's own pixel there (up to the rounding of the projection, which is checked, not
         // assumed), so its feature vector is fetched once per chunk instead of once per load

@@ -452,6 +452,10 @@ void k_sweep_map(
         }
     }
     RN_PHASE_MARK(1);                      // ray index + segment loads
+    if (RN_SWEEP_STOP == 1) {
+        if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     if (SIM == 0) {
         for (int k = lane; k < p.D; k += WAVE) Sl[k] = S_in[(size_t)r * p.D + k];
     } else {
@@ -461,10 +465,18 @@ void k_sweep_map(
             sweep_coop<NV, LPS, RESIDENT>(p, fv, fv_table, P, s, e, lane, Sl);
         wave_sync();
         RN_PHASE_MARK(2);                  // projection + feature gathers + pair sums
+        if (RN_SWEEP_STOP == 12 || RN_SWEEP_STOP == 2) {
+            if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         softmax_column<RESIDENT>(p.D, lane, Sl);
     }
     wave_sync();
     RN_PHASE_MARK(3);                      // softmax
+    if (RN_SWEEP_STOP == 3) {
+        if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
 
     if (MAPMODE == 0) {
         for (int k = lane; k < p.D; k += WAVE) S_planes[(size_t)r * p.D + k] = Sl[k];
@@ -519,6 +531,10 @@ void k_sweep_map(
         map_planes_to_voxels<PACKED, RESIDENT, PACKED, MAP_TABLE>(p, axes, vrow, count, s, e, Sl,
                                                                   vals, lane, n_staged, pos);
     RN_PHASE_MARK(4);                      // planes -> voxels
+    if (RN_SWEEP_STOP == 4) {
+        if (lane == 0) out[0] = srsum;
+        return;
+    }
     if (MAPMODE == 1) {
         for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
     } else {
@@ -530,6 +546,10 @@ void k_sweep_map(
             sum += v;
         }
         sum = __builtin_amdgcn_rcpf(wave_sum(sum));
+        if (RN_SWEEP_STOP == 45) {
+            if (lane == 0) out[0] = sum;
+            return;
+        }
         if (MAPMODE == 3) {
             first_sweep_messages(count, lane, vals, sum, vals + p.M, vals + 2 * p.M, o_first, out,
                                  msgs_out + (size_t)r * p.M);

@@ -49,18 +49,30 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     X(25, "v_sqrt_f32", asm volatile("v_sqrt_f32 %0, %0" : "+v"(a.x)))                              \
     X(26, "v_fma_f64", asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d) : "v"(dm)))                \
     X(27, "v_readlane_b32", asm volatile("v_readlane_b32 %0, %1, 63" : "=s"(sg) : "v"(a.x)))        \
-    X(28, "v_mfma_f32_32x32x2f32", asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc16) : "v"(a.x), "v"(a.y)))
+    X(28, "v_mfma_f32_32x32x2f32", asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc16) : "v"(a.x), "v"(a.y))) \
+    X(29, "v_cndmask (vcc)", asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a.x) : "v"(c)))  \
+    X(30, "v_cndmask (2 sgpr masks)", if (i & 1) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a.x) : "v"(c), "s"(mask_a)); \
+                                      else asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a.x) : "v"(c), "s"(mask_b))) \
+    X(31, "v_mfma_f32_4x4x1_16b", asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(q) : "v"(a.x), "v"(a.y))) \
+    X(32, "v_mfma_f32_16x16x4_f32", asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(q) : "v"(a.x), "v"(a.y))) \
+    X(33, "v_mfma_f32_16x16x1_4b", asm volatile("v_mfma_f32_16x16x1_4b_f32 %0, %1, %2, %0" : "+v"(acc16) : "v"(a.x), "v"(a.y)))
 
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 template <int KIND>
 __global__ void k_stream(int outer, float seed, float *out, unsigned long long *cycles) {
     f2 acc[UNROLL];
     double dd[UNROLL];
     f16v acc16 = {0.f};
+    f4v acc4[UNROLL];
     int sg = 0;
+    // (two lane masks in SGPR pairs the compiler cannot fold: the select's cost without a chain
+    // through ONE mask register -- round 4's row read 23.6 cycles, the benchmark's artefact)
+    unsigned long long mask_a, mask_b;
+    asm volatile("s_mov_b64 %0, 0x55555555\n\ts_mov_b64 %1, 0x33333333\n\ts_mov_b64 vcc, 0x0f0f0f0f" : "=s"(mask_a), "=s"(mask_b) : : "vcc");
 #pragma unroll
-    for (int i = 0; i < UNROLL; i++) { acc[i] = f2{seed + i + threadIdx.x, -(seed + i)}; dd[i] = seed + i; }
+    for (int i = 0; i < UNROLL; i++) { acc[i] = f2{seed + i + threadIdx.x, -(seed + i)}; dd[i] = seed + i; acc4[i] = f4v{0.f, 0.f, 0.f, 0.f}; }
     const float m = 0.999f, c = 1e-3f;
     const f2 mm = {m, m}, cc = {c, c};
     const double dm = 0.999;
@@ -72,6 +84,7 @@ __global__ void k_stream(int outer, float seed, float *out, unsigned long long *
             for (int i = 0; i < UNROLL; i++) {
                 f2 &a = acc[i];
                 double &d = dd[i];
+                f4v &q = acc4[i];
 #define X(ID, NAME, STMT) if (KIND == ID) { STMT; }
                 RN_KINDS(X)
 #undef X
@@ -81,7 +94,7 @@ __global__ void k_stream(int outer, float seed, float *out, unsigned long long *
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = (float)sg + acc16[0] + acc16[7];
 #pragma unroll
-    for (int i = 0; i < UNROLL; i++) s += acc[i].x + acc[i].y + (float)dd[i];
+    for (int i = 0; i < UNROLL; i++) s += acc[i].x + acc[i].y + (float)dd[i] + acc4[i][0] + acc4[i][3];
     if (s == 123.456f) out[0] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) cycles[0] = t1 - t0;
 }

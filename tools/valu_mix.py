@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Static VALU instruction mix of the path's kernels, weighted with the MEASURED issue cost of
-each instruction class (tools/valu_issue_bench.hip -> profiles/r04_valu_issue_bench.txt):
+each instruction class (tools/valu_issue_bench.hip -> profiles/r05_valu_issue_bench.txt).  Since
+round 5 bench.py no longer needs this estimate for the kernel it reports on: its counter pass
+measures the VALUs' busy cycles per executed instruction directly (4 x SQ_ACTIVE_INST_VALU /
+SQ_INSTS_VALU = 4.09 for k_sweep_map at config 2, against 3.80 from this static histogram); the
+table stays as the fall-back for runs without counters and for the other kernels.
 
     python tools/valu_mix.py            # compiles the library to assembly (hipcc -S, ~40 s), writes
                                         # profiles/valu_issue.json
@@ -24,7 +28,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from raynet_amd import _lib      # noqa: E402
 
-# measured, profiles/r04_valu_issue_bench.txt (8 wavefronts per SIMD; two runs on two boxes)
+# measured, profiles/r05_valu_issue_bench.txt (8 wavefronts per SIMD; r04: two runs on two boxes).
+# v_cndmask_b32 with its mask in an SGPR pair issues like the rest of "std" (4.1 cycles); a stream of
+# 1024 selects that all read VCC runs at 22.9 cycles each (round 4's 23.6: the same artefact of the
+# benchmark's stream, not what a compare + select pair costs in a kernel -- the kernels' measured
+# mean of 4.09 cycles per executed instruction leaves no room for it).
 CYCLES = {"fast": 2.6, "std": 4.12, "trans": 8.12}
 CYCLES_RANGE = {"fast": [2.2, 2.9], "std": [4.05, 4.85], "trans": [8.1, 8.15]}
 FAST = re.compile(r"^v_(add|sub|subrev|mul|fma|fmac|mac)_f32(_e32|_e64)?$|^v_(add|sub|subrev)_u32(_e32|_e64)?$|"
