@@ -30,6 +30,9 @@ sharded contiguously over the ranks; each rank scatters into its own zeroed
 accumulator and one all-reduce (RCCL) per BP iteration merges them before the
 prior is added once.
 """
+import ctypes
+import weakref
+
 import numpy as np
 import torch
 
@@ -629,7 +632,7 @@ class RayNetForwardPass(ForwardPass):
         plan = dict(key=key, ptrs=ptrs, scene=scene, cams=cams, prior=self._prior(), dirty=False,
                     cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
                     balance=balance, shards=shards, npad=npad, shared=shared,
-                    patch_rows=patch_rows, orders={}, stitch=None, fast=None, slot=0, direct=False,
+                    patch_rows=patch_rows, orders={}, stitch=None, fast=None, direct=False,
                     along_rows=self._along_rows,
                     table=torch.tensor(ptrs, dtype=torch.int64).to(dev) if V else None)
         self._plan_buffers(ctx, plan, refs, old_bytes)
@@ -661,18 +664,6 @@ class RayNetForwardPass(ForwardPass):
                 order = row_major_order(shards[0][0], H, W) if shards[0][0].numel() else None
             elif "rows" in modes:
                 fast_ok = False           # per-image schedules: the launch-by-launch path
-        if fast_ok and patch_rows and opt.sweep_tile is not None and shards[0][0].numel():
-            # the plane sweep's own schedule over patch-ordered rows: which ray the i-th
-            # wavefront takes (results do not depend on it)
-            ridx = shards[0][0].to(torch.int64)
-            tx, ty = opt.sweep_tile
-            x, y = ridx // H, ridx % H
-            along = bool(plan["along_rows"])
-            if along:
-                key = (((y // ty) * ((W + tx - 1) // tx) + x // tx) * ty + y % ty) * tx + x % tx
-            else:
-                key = (((x // tx) * ((H + ty - 1) // ty) + y // ty) * tx + x % tx) * ty + y % ty
-            order = torch.argsort(key).to(torch.int32)
         if dist is not None and world > 1 and hasattr(ctx, "scene_run"):
             # the two paths exchange differently (per-image all-gathers / one): every rank must
             # take the same one, and a rank's HBM budget may have decided otherwise
@@ -690,33 +681,69 @@ class RayNetForwardPass(ForwardPass):
                 V, npad, shards[0][0], plan["table"], cam_dev, plan["vox"], plan["rvc"],
                 plan["Sr"], plan["msgs"], plan["acc_a"], plan["acc_b"], plan["depth"],
                 plan["prior"], patch_rows, acc_fixed=plan["acc_part"] if plan["fixed"] else None,
-                order=order, sweep_xcd_chunk=opt.sweep_xcd_chunk,
+                order=order,
                 **({"depth_image": plan["maps_dev"]} if plan["direct"] else {}))
         if not self._filter_out_rays:
             self._plan = plan
         return plan
 
     # -- where the maps land -------------------------------------------------------------------
-    def _host_set(self, V, HW, cuda):
-        """One set of pinned host maps: the tensor and one flat ndarray view per image."""
-        h = torch.empty((V, HW), dtype=torch.float32, pin_memory=cuda)
-        return h, [h[k].numpy() for k in range(V)]
+    # -- where the maps land -------------------------------------------------------------------
+    # A pass's maps are written by the GPU straight into pinned host memory (the stitch kernel /
+    # the copies of the epilogue).  What the caller gets (PathOptions.maps):
+    #   "lease" (default)  arrays that ARE that pinned memory, each holding a lease on it: the
+    #            memory goes back to the plan's pool when the array -- and every view or slice
+    #            made of it -- has been garbage-collected (weakref.finalize on the array's buffer
+    #            owner; no reference counts are looked at).  Until then no later pass touches it:
+    #            a pass takes a set of maps nobody holds a lease on, or a new one.  The reference's
+    #            semantics -- fresh arrays from `.get()`, forward_pass.py:739-744 -- without a
+    #            copy; a caller that drops a pass's maps before the next pass (bench.py, the
+    #            script) stays on one set, one that keeps the last map alternates between two.
+    #   "copy"   pageable copies out of ONE pinned scratch set (also what "lease" falls back to
+    #            when a caller holds leases on MAX_LEASED_SETS sets: pinned memory is not for
+    #            hoarding).
+    MAX_LEASED_SETS = 4
+
+    @staticmethod
+    def _new_set(V, HW, cuda):
+        return dict(host=torch.empty((V, HW), dtype=torch.float32, pin_memory=cuda), leases=0)
+
+    def _take_set(self, plan, V, HW, cuda):
+        """-> (key, set, leased): a set of pinned maps this pass may write -- one nobody holds a
+        lease on (key = its index in the pool), a new one, or the scratch set (key -1, copies)."""
+        if self.options.maps == "lease":
+            pool = plan["sets"]
+            for i, st in enumerate(pool):
+                if st["leases"] == 0:
+                    return i, st, True
+            if len(pool) < self.MAX_LEASED_SETS:
+                pool.append(self._new_set(V, HW, cuda))
+                return len(pool) - 1, pool[-1], True
+        if plan["scratch"] is None:
+            plan["scratch"] = self._new_set(V, HW, cuda)
+        return -1, plan["scratch"], False
+
+    @staticmethod
+    def _lease(st, k):
+        """Image k of the set as an ndarray that owns a lease on the set's memory."""
+        row = st["host"][k]
+        owner = (ctypes.c_float * row.numel()).from_address(row.data_ptr())
+        st["leases"] += 1
+
+        def release(st=st):         # (keeps the set -- and its pinned tensor -- alive until then)
+            st["leases"] -= 1
+        weakref.finalize(owner, release)
+        return np.frombuffer(owner, dtype=np.float32)
 
     def _epilogue_buffers(self, plan, refs, H, W, dev, world, rank, collective):
-        """Plan-owned output side: per-image events, the device-side pixel-order maps, and TWO
-        sets of pinned host maps -- a pass allocates nothing.  What a pass yields
-        (PathOptions.maps): fresh arrays like the reference's `.get()`, forward_pass.py:739-744
-        ("copy", the default: one set is enough), or views of the two sets used in turns, valid
-        until the second-next pass over the same plan ("view")."""
-        if "host" in plan:
+        """Plan-owned output side: per-image events, the device-side pixel-order maps, the pool of
+        pinned host maps (see _take_set) -- a pass allocates nothing once the pool has the sets
+        its caller's habits need."""
+        if "sets" in plan:
             return
         cuda = dev.type == "cuda"
         V, HW = len(refs), H * W
-        copy_maps = self.options.maps == "copy"
-        sets = [self._host_set(V, HW, cuda) for _ in range(1 if copy_maps else 2)]
-        plan["host"] = [a for a, _ in sets]
-        plan["host_root"] = [b for _, b in sets]
-        plan["copy_maps"] = copy_maps
+        plan["sets"], plan["scratch"] = [], None
         plan["graphs"] = {}
         plan["passes"] = 0
         if "maps_dev" not in plan:
@@ -771,11 +798,11 @@ class RayNetForwardPass(ForwardPass):
             ev.record()
             self.trace.append((name, begin, ev))
 
-    def _emit_image(self, plan, k, st, slot):
+    def _emit_image(self, plan, k, st, host_set):
         """One GPU, no process group: image k's depth rows (just enqueued on the current stream)
         -> pixel order -> pinned host memory, on side streams: under the depth sweep of image
         k + 1 (the reorder on the first side stream, the copy to the host on the second)."""
-        host = plan["host"][slot][k]
+        host = host_set[k]
         rows = plan["depth"][st["row0"]:st["row0"] + st["n"]]
         side, copy = self._side_stream, self._copy_stream
         plan["ev_ready"][k].record()
@@ -793,14 +820,14 @@ class RayNetForwardPass(ForwardPass):
             plan["ev_done"][k].record()
         plan["wait_ev"][k] = plan["ev_done"][k]
 
-    def _emit_direct(self, plan, groups, slot):
+    def _emit_direct(self, plan, groups, host_set):
         """The maps of the image groups [a, b) -- written in pixel order by their depth launches,
         ev_ready[a] recorded behind each -- go to the pinned host maps, one copy per group."""
         copy = self._copy_stream
         with torch.cuda.stream(copy):
             for a, b in groups:
                 copy.wait_event(plan["ev_ready"][a])
-                plan["host"][slot][a:b].copy_(plan["maps_dev"][a:b], non_blocking=True)
+                host_set[a:b].copy_(plan["maps_dev"][a:b], non_blocking=True)
                 plan["ev_done"][a].record()
                 for k in range(a, b):
                     plan["wait_ev"][k] = plan["ev_done"][a]
@@ -839,7 +866,7 @@ class RayNetForwardPass(ForwardPass):
             self._mark("exchange", False)
         ctx.scene_run(fast, _lib.RN_RUN_COMBINE, it)
 
-    def _run_plan_path(self, plan, ctx, refs, dist, world, slot, captured=False):
+    def _run_plan_path(self, plan, ctx, refs, dist, world, host_set, captured=False):
         """One pass as phases of the C plan (include/raynet_hip.h, rn_scene_run): 1 + T calls
         for the K1 prefix and the T BP iterations, the exchange between them, then the depth
         sweep and the maps' way to the host.  Eager, or -- `captured` -- recorded into a HIP graph
@@ -872,7 +899,7 @@ class RayNetForwardPass(ForwardPass):
                 else:
                     ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, a)
                 plan["ev_ready"][a].record()
-            self._emit_direct(plan, groups, slot)
+            self._emit_direct(plan, groups, host_set)
         elif dist is not None:
             # sharded rays, owner-only maps (_epilogue_buffers): ONE depth launch over all of
             # this rank's rows, ONE all-gather of the ranks' rows, ONE stitch launch on an owner
@@ -888,7 +915,7 @@ class RayNetForwardPass(ForwardPass):
                 mine = rows["mine"]
                 if mine:
                     HW = plan["maps_dev"].shape[1]
-                    host = plan["host"][slot].view(-1)
+                    host = host_set.view(-1)
                     ctx.stitch_rows(rows["recv"], rows["table"],
                                     host[mine[0] * HW:(mine[-1] + 1) * HW])
                 plan["ev_done"][0].record()
@@ -899,13 +926,13 @@ class RayNetForwardPass(ForwardPass):
             # them), the last on its own -- long enough for the others' maps to leave under it.
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, 0 | ((V - 1) << 16))
             for j in range(V - 1):
-                self._emit_image(plan, j, per_image[refs[j]], slot)
+                self._emit_image(plan, j, per_image[refs[j]], host_set)
             ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, V - 1)
-            self._emit_image(plan, V - 1, per_image[refs[V - 1]], slot)
+            self._emit_image(plan, V - 1, per_image[refs[V - 1]], host_set)
         else:
             for k, r in enumerate(refs):
                 ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, k)
-                self._emit_image(plan, k, per_image[r], slot)
+                self._emit_image(plan, k, per_image[r], host_set)
         if captured:
             cur = torch.cuda.current_stream(ctx.device)
             cur.wait_stream(self._side_stream)
@@ -1026,15 +1053,13 @@ class RayNetForwardPass(ForwardPass):
             self._epilogue_buffers(plan, refs, H, W, dev, world, rank, dist is not None)
             V = len(refs)
             self._scatter_work_list(plan, ctx)
-            # which pinned set this pass writes: "copy" hands out fresh arrays (one set);
-            # "view" hands out views of the two sets in turns, so that a pass's maps outlive
-            # the next pass
-            slot = 0 if plan["copy_maps"] else plan["slot"] ^ 1
-            plan["slot"] = slot
+            # the pinned maps this pass writes: a set nobody holds a lease on (see _take_set)
+            set_key, mset, leased = self._take_set(plan, V, H * W, dev.type == "cuda")
+            host_set = mset["host"]
             # (a pass whose launches or exchanges are bracketed by events runs eagerly)
             eager = self.trace is not None or getattr(ctx, "prof_active", False) or \
                 self.options.capture == "off"
-            gkey = (slot, self.bp_iterations)       # (what a recorded step has baked in)
+            gkey = (set_key, self.bp_iterations)    # (what a recorded step has baked in)
             graph = None if eager else plan["graphs"].get(gkey)
             if graph is None and not eager and self._capturable(plan, ctx, dist):
                 # the whole step -- phases, exchanges, epilogue -- as ONE graph (per host set):
@@ -1042,7 +1067,7 @@ class RayNetForwardPass(ForwardPass):
                 try:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
-                        self._run_plan_path(plan, ctx, refs, dist, world, slot, captured=True)
+                        self._run_plan_path(plan, ctx, refs, dist, world, host_set, captured=True)
                     plan["graphs"][gkey] = graph
                 except Exception as e:        # a transport / runtime that cannot be captured
                     import warnings
@@ -1058,16 +1083,14 @@ class RayNetForwardPass(ForwardPass):
                 self._acc_flat = plan["acc_b" if (T - 1) & 1 else "acc_a"]
                 self._acc_bias = 0.0 if plan["fixed"] else plan["prior"]
             else:
-                self._run_plan_path(plan, ctx, refs, dist, world, slot)
+                self._run_plan_path(plan, ctx, refs, dist, world, host_set)
             self.captured = graph is not None
             plan["passes"] += 1
             for r in refs:
                 st = per_image[r]
                 self.messages.put(r, st["msgs"], st["rvc"])
                 self.voxel_count[r] = st["rvc"]
-            roots = plan["host_root"][slot]
             owners = plan["owners"]
-            copy = plan["copy_maps"]
             spin = self.options.spin_wait
             for k, r in enumerate(refs):
                 self.ref_idx = r
@@ -1080,8 +1103,9 @@ class RayNetForwardPass(ForwardPass):
                         pass
                 else:
                     ev.synchronize()
-                a = roots[k].copy() if copy else roots[k]
+                a = self._lease(mset, k) if leased else host_set[k].numpy().copy()
                 yield a.reshape(W, H).T
+                del a
             self._pass_complete = True
             return
         if getattr(ctx, "_scatter_items", None) is not None:

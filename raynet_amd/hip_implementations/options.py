@@ -34,11 +34,6 @@ class PathOptions:
     ray_tile: Optional[Tuple[int, int]] = (16, 16)   # pixel patch per 256 rows; None: ray-index order
     tile_along: str = "auto"          # patches enumerated along image "rows" / "cols"; "auto": by the epipoles
     sweep_reorder: bool = True        # epipolar row-major schedule of the plane sweep for ray-index rows
-    sweep_tile: Optional[Tuple[int, int]] = None   # schedule of the plane sweep over patch-ordered rows:
-    #                                   consecutive wavefronts take the rays of (x, y)-pixel tiles of this
-    #                                   size instead of the rows as they lie (None); with sweep_xcd_chunk
-    #                                   rays (0: the library's 2048) side by side on one XCD
-    sweep_xcd_chunk: int = 0
     scatter_items: bool = True        # the box scatter takes a work list built from the rays' voxel
     #                                   counts (a tile's live chunks in pieces, longest first) from a
     #                                   plan's second pass on, instead of tiles x a fixed split
@@ -54,10 +49,12 @@ class PathOptions:
     #                                   ahead of a 6.7 ms step anyway; a 1 ms step of eight ranks does not
     #                                   wait for it: -5 %).  RCCL's collectives are captured with the
     #                                   launches; other transports keep the eager schedule
-    maps: str = "copy"                # what a pass yields: "copy" = fresh arrays like the reference's
-    #                                   .get() (forward_pass.py:739-744); "view" = views of the plan's two
-    #                                   pinned host sets, used in turns -- valid until the second-next pass
-    #                                   over the same plan (zero-copy, for callers that consume a map at once)
+    maps: str = "lease"               # what a pass yields: "lease" = arrays that ARE the pinned host
+    #                                   memory the GPU wrote, each holding a lease that ends when the
+    #                                   array and all its views are garbage-collected -- no later pass
+    #                                   touches leased memory (forward_pass._take_set): the reference's
+    #                                   fresh-array semantics (.get(), forward_pass.py:739-744) without a
+    #                                   copy; "copy" = pageable copies
     # ---- memory ---------------------------------------------------------------------------
     resident_gb: float = 0.0          # HBM budget of the resident schedule; 0: 90 % of what is free
     # ---- multi-GPU ------------------------------------------------------------------------
@@ -79,8 +76,6 @@ class PathOptions:
         "RAYNET_RAY_TILE": ("ray_tile", _tile),
         "RAYNET_TILE_ALONG": ("tile_along", str),
         "RAYNET_SWEEP_REORDER": ("sweep_reorder", _flag),
-        "RAYNET_SWEEP_TILE": ("sweep_tile", _tile),
-        "RAYNET_SWEEP_XCD_CHUNK": ("sweep_xcd_chunk", int),
         "RAYNET_SLAB_BOXES": ("slab_boxes", _flag),
         "RAYNET_SCATTER_ITEMS": ("scatter_items", _flag),
         "RAYNET_PLAN_PATH": ("plan_path", _flag),
@@ -104,15 +99,12 @@ class PathOptions:
     def __post_init__(self):
         if self.ray_tile is not None:
             self.ray_tile = (int(self.ray_tile[0]), int(self.ray_tile[1]))
-        if self.sweep_tile is not None:
-            self.sweep_tile = (int(self.sweep_tile[0]), int(self.sweep_tile[1]))
-        assert self.sweep_xcd_chunk >= 0 and self.sweep_xcd_chunk % 4 == 0
         assert self.tile_along in ("auto", "rows", "cols"), self.tile_along
         assert self.shard in ("voxels", "rays"), self.shard
         assert self.exchange in ("allreduce", "reduce_scatter"), self.exchange
         assert self.scatter_mode in (-1, 0, 2) and self.box_level in (0, 1, 2)
         assert self.overlap in (0, 1, 2)
-        assert self.maps in ("copy", "view"), self.maps
+        assert self.maps in ("lease", "copy"), self.maps
         assert self.capture in ("auto", "on", "off"), self.capture
 
     @classmethod
@@ -134,7 +126,6 @@ class PathOptions:
     def as_dict(self):
         d = asdict(self)
         d["ray_tile"] = "%dx%d" % self.ray_tile if self.ray_tile else None
-        d["sweep_tile"] = "%dx%d" % self.sweep_tile if self.sweep_tile else None
         return d
 
     def context_options(self):

@@ -36,10 +36,16 @@ class SimpleCNN(nn.Module):
     # 11 x 11 patches around the rays' projected sample points, 32,000 per view and call,
     # tf_implementations/forward_backward_pass.py:177-182) and takes the row-matrix path.
     PATCH_MAX_SIDE, PATCH_MIN_BATCH = 16, 2048
+    # "auto": by the shape rule above; True / False: always / never the row-matrix path (a caller
+    # that knows what it feeds -- the batch provider of config 5 -- need not rely on the guess)
+    patch_path = "auto"
 
     def forward(self, x):           # NCHW
-        if x.dim() == 4 and max(x.shape[-2:]) <= self.PATCH_MAX_SIDE and \
-                x.shape[0] >= self.PATCH_MIN_BATCH and min(x.shape[-2:]) >= 3:
+        use = self.patch_path
+        if use == "auto":
+            use = x.dim() == 4 and max(x.shape[-2:]) <= self.PATCH_MAX_SIDE and \
+                x.shape[0] >= self.PATCH_MIN_BATCH
+        if use and x.dim() == 4 and min(x.shape[-2:]) >= 3:
             return self.forward_patches(x)
         return self.net(x)
 
@@ -54,18 +60,23 @@ class SimpleCNN(nn.Module):
         product of 9 C terms (tests/test_models.py).  NCHW in, NCHW out."""
         from torch.nn import functional as F
         y = x.permute(0, 2, 3, 1)                                  # [B, h, w, C] (a view)
-        for i, (conv, bn) in enumerate(self._blocks()):
+        blocks = self._blocks()
+        for i, (conv, bn) in enumerate(blocks):
             B, h, w, C = y.shape
             # [B, h-2, w-2, C, 3, 3] windows -> rows [B (h-2) (w-2), 3 * 3 * C] in (ky, kx, c) order
             cols = y.unfold(1, 3, 1).unfold(2, 3, 1).permute(0, 1, 2, 4, 5, 3)
             rows = cols.reshape(B * (h - 2) * (w - 2), 9 * C)
             wm = conv.weight.permute(2, 3, 1, 0).reshape(9 * C, conv.out_channels)
             out = torch.addmm(conv.bias, rows, wm)
+            # nn.BatchNorm2d.forward's own bookkeeping: momentum None = cumulative average
+            factor = 0.0 if bn.momentum is None else bn.momentum
             if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)
+                if bn.momentum is None:
+                    factor = 1.0 / float(bn.num_batches_tracked)
             out = F.batch_norm(out, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                               bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
-            if i < 4:
+                               bn.training or not bn.track_running_stats, factor, bn.eps)
+            if i + 1 < len(blocks):         # the last block has no ReLU (models.py:90-111)
                 out = F.relu(out)
             y = out.view(B, h - 2, w - 2, conv.out_channels)
         return y.permute(0, 3, 1, 2)

@@ -112,7 +112,10 @@ def main(argv=None):
     start, end = args.start_end
     ref_idx = start
     for S in fp.forward_pass(scene, (start, end, args.skip_every + 1)):
-        np.save(os.path.join(args.output_directory, "depth_%03d.npy" % (ref_idx,)), S)
+        # (with a process group the rays are sharded and image k's map is assembled by ONE rank,
+        # forward_pass.map_owner: the other ranks get None for it and leave its file alone)
+        if S is not None:
+            np.save(os.path.join(args.output_directory, "depth_%03d.npy" % (ref_idx,)), S)
         ref_idx += args.skip_every + 1
     return 0
 

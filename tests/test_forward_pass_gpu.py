@@ -399,7 +399,7 @@ def test_captured_step_replays_the_eager_pass(torch):
     cls = get_forward_pass_factory("raynet")
     for T in (3, 2):
         fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, bp_iterations=T,
-                 options=PathOptions(deterministic=True, capture="on", maps="view" if T == 3 else "copy"))
+                 options=PathOptions(deterministic=True, capture="on", maps="lease" if T == 3 else "copy"))
         first = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
         acc = fp.accumulator.cpu().numpy()
         assert not fp.captured
@@ -413,8 +413,9 @@ def test_captured_step_replays_the_eager_pass(torch):
             assert np.array_equal(fp.accumulator.cpu().numpy(), acc)
             if sum(seen) >= 4:
                 break
-        # one graph per pinned host set: two sets of views in turns, one set behind fresh copies
-        assert seen[-1] and seen[-2] and len(fp._plan["graphs"]) == (2 if T == 3 else 1)
+        # one graph per pinned host set a pass wrote: this caller drops a pass's maps before the
+        # next pass, so leased maps and copies alike stay on ONE set
+        assert seen[-1] and seen[-2] and len(fp._plan["graphs"]) == 1
         # another iteration count on the same plan is another step: never the recorded one's replay
         fp.bp_iterations = T - 1
         fewer = np.stack([m.copy() for m in fp.forward_pass(scene, (0, 5, 1))])
@@ -438,11 +439,13 @@ def test_captured_step_replays_the_eager_pass(torch):
 
 
 def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
-    """PathOptions.maps.  "copy" (default): fresh arrays, like the reference's `.get()`
-    (forward_pass.py:739-744) -- whatever a caller keeps stays what it was.  "view": the
-    documented zero-copy lifetime (views of two pinned sets in turns: the second-next pass
-    overwrites).  bp_iterations is not part of the plan key, so passes with different T share
-    one plan -- and differ."""
+    """PathOptions.maps.  "lease" (default): a pass yields arrays that ARE the pinned host memory
+    the GPU wrote (no copy) and hold a lease on it until they -- and every view or slice of them --
+    are garbage-collected; no later pass touches leased memory, so whatever a caller keeps stays
+    what it was, like the reference's fresh arrays from `.get()` (forward_pass.py:739-744).
+    Dropped maps give their set back to the plan's pool.  "copy": pageable copies.  bp_iterations
+    is not part of the plan key, so passes with different T share one plan -- and differ."""
+    import gc
     from raynet_amd.forward_pass import get_forward_pass_factory
     from raynet_amd.hip_implementations.options import PathOptions
     from raynet_amd.synthetic import make_synthetic_scene
@@ -456,26 +459,48 @@ def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
         return list(fp.forward_pass(scene, (0, 5, 1)))
 
     truth = {}
-    assert PathOptions().maps == "copy"
-    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True))
+    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True, maps="copy"))
     for T in (3, 1, 2):
         truth[T] = np.stack(run(fp, T))
     assert not np.array_equal(truth[3], truth[1])
-    a, b, c = run(fp, 3), run(fp, 1), run(fp, 2)
-    assert not any(np.shares_memory(x, y) for x in a for y in b + c)
-    assert np.array_equal(np.stack(a), truth[3]) and np.array_equal(np.stack(b), truth[1])
-    keep = run(fp, 1)[2][5:9, 7:11]                 # a slice of a map, kept across passes
-    run(fp, 2)
-    run(fp, 3)
-    assert np.array_equal(keep, truth[1][2][5:9, 7:11])
+    a, b = run(fp, 3), run(fp, 1)
+    assert not any(np.shares_memory(x, y) for x in a for y in b)
+    assert fp._plan["sets"] == [] and fp._plan["scratch"] is not None
 
-    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True, maps="view"))
+    assert PathOptions().maps == "lease"
+    fp = cls(bank, gp, "sample_in_bbox", (H, W), 0, options=PathOptions(deterministic=True))
+    for T in (3, 1, 2, 3):                  # a caller that lets go of a pass's maps: ONE set
+        got = np.stack(run(fp, T))          # (np.stack copies; the leases end here)
+        assert np.array_equal(got, truth[T])
+    pool = fp._plan["sets"]
+    assert len(pool) == 1 and pool[0]["leases"] == 0 and fp._plan["scratch"] is None
     a = run(fp, 3)
-    b = run(fp, 1)
-    assert np.array_equal(np.stack(a), truth[3])                   # outlives the next pass
-    c = run(fp, 2)
-    assert all(np.shares_memory(x, y) for x, y in zip(a, c))       # the documented lifetime
-    assert np.array_equal(np.stack(a), truth[2]) and np.array_equal(np.stack(b), truth[1])
+    base = pool[0]["host"]
+    lo, hi = base.data_ptr(), base.data_ptr() + base.numel() * 4
+    assert all(lo <= x.ctypes.data < hi for x in a)          # zero-copy: the pinned memory itself
+    keep = a[2][5:9, 7:11]                  # a slice of one map, kept; the rest dropped
+    del a
+    gc.collect()
+    assert pool[0]["leases"] == 1
+    b = run(fp, 1)                          # set 0 is leased: another set
+    assert len(pool) == 2 and np.array_equal(np.stack(b), truth[1])
+    c = run(fp, 2)                          # `keep` holds set 0, `b` set 1: a third
+    assert len(pool) == 3 and np.array_equal(np.stack(c), truth[2])
+    assert np.array_equal(keep, truth[3][2][5:9, 7:11]) and np.array_equal(np.stack(b), truth[1])
+    del keep, b, c
+    gc.collect()
+    assert [st["leases"] for st in pool] == [0, 0, 0]
+    d = run(fp, 3)                          # back on set 0, nothing new
+    assert len(pool) == 3 and pool[0]["leases"] == 5 and np.array_equal(np.stack(d), truth[3])
+    # a caller that hoards: beyond MAX_LEASED_SETS sets of pinned memory it gets pageable copies
+    hoard = [d] + [run(fp, 1 + i % 3) for i in range(fp.MAX_LEASED_SETS + 1)]
+    assert len(pool) == fp.MAX_LEASED_SETS and fp._plan["scratch"] is not None
+    last = hoard[-1]
+    assert not any(st["host"].data_ptr() <= x.ctypes.data < st["host"].data_ptr() + st["host"].numel() * 4
+                   for st in pool for x in last)
+    for i, maps in enumerate(hoard[1:]):
+        assert np.array_equal(np.stack(maps), truth[1 + i % 3])
+    assert np.array_equal(np.stack(hoard[0]), truth[3])
 
 
 def test_pixel_order_maps_straight_from_the_depth_sweep(torch):

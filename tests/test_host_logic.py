@@ -174,3 +174,39 @@ def test_scatter_work_list_stops_where_an_item_cannot_name_the_tile():
     assert all(int(v) >= 0 for v in items) and got == [(tiles - 1, 0, 1), (tiles - 1, 1, 1)]
     rvc = torch.cat([rvc, torch.full((128,), 40, dtype=torch.int32)])
     assert scatter_work_list(rvc, 96, 0, target_items=2048) is None
+
+
+def test_leased_maps_return_their_set_when_the_last_view_dies():
+    """forward_pass._take_set / _lease (PathOptions.maps = "lease"): an array handed out holds its
+    set until it and every view of it are gone; a pass never gets a set somebody holds; beyond
+    MAX_LEASED_SETS the caller gets the scratch set (copies).  No GPU needed: plain host tensors."""
+    import gc
+    from raynet_amd.forward_pass import RayNetForwardPass
+    from raynet_amd.hip_implementations.options import PathOptions
+    fp = RayNetForwardPass.__new__(RayNetForwardPass)
+    fp.options = PathOptions()
+    plan = dict(sets=[], scratch=None)
+    V, HW = 3, 8
+    k0, s0, leased = fp._take_set(plan, V, HW, False)
+    assert (k0, leased) == (0, True) and s0["leases"] == 0
+    s0["host"].copy_(__import__("torch").arange(V * HW, dtype=__import__("torch").float32).view(V, HW))
+    a = [fp._lease(s0, k) for k in range(V)]
+    assert s0["leases"] == 3 and a[1][2] == 10.0 and a[1].ctypes.data == s0["host"][1].data_ptr()
+    view = a[2].reshape(4, 2).T[1:, 1:]
+    del a
+    gc.collect()
+    assert s0["leases"] == 1                         # the slice of image 2 is still out there
+    k1, s1, _ = fp._take_set(plan, V, HW, False)
+    assert k1 == 1 and s1 is not s0
+    del view
+    gc.collect()
+    assert s0["leases"] == 0 and fp._take_set(plan, V, HW, False)[0] == 0
+    held = []
+    for i in range(fp.MAX_LEASED_SETS + 2):
+        k, st, leased = fp._take_set(plan, V, HW, False)
+        if leased:
+            held.append(fp._lease(st, 0))
+        assert (k == -1) == (i >= fp.MAX_LEASED_SETS) and leased == (k >= 0)
+    assert len(plan["sets"]) == fp.MAX_LEASED_SETS and plan["scratch"] is not None
+    fp.options = PathOptions(maps="copy")
+    assert fp._take_set(plan, V, HW, False)[0] == -1
