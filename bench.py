@@ -160,7 +160,7 @@ def live_pmc(config, family, budget_s=180.0):
             cmd = [rocprof, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv",
                                                   "-d", d, "-o", "p", "--", sys.executable,
                                                   os.path.abspath(__file__), "--steps", "1",
-                                                  "--warmup", "1", "--no-cpu-baseline",
+                                                  "--warmup", "1", "--no-cpu-baseline", "--no-config4",
                                                   "--pmc", "off", "--config", config]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL, timeout=min(left, 60.0))
@@ -226,12 +226,15 @@ def main():
                     help="launches bracketed by HIP events inside the timed region: those of the "
                          "dominant kernel family (the roofline block), or all of them")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-config4", dest="also_config4", action="store_false",
+                    help="skip the side measurement of BASELINE.json configs[3] (other_configs)")
     ap.add_argument("--pmc", default="live", choices=["live", "table", "off"],
                     help="roofline.traffic / valu_insts of the dominant kernel: measured now by "
                          "rocprofv3 --pmc passes of this script spawned from this run (live; N = 1 "
                          "only, falls back to the table), read from profiles/pmc_traffic.json "
                          "(table), or left out (off)")
     args = ap.parse_args()
+    t_wall = {"start": time.perf_counter()}
 
     import torch
     import torch.distributed as dist
@@ -269,6 +272,7 @@ def main():
     fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W),
                                             args.rays_batch, schedule=args.schedule)
     images_range = (0, V, 1)
+    t_wall["scene"] = time.perf_counter()
 
     def step():
         out = None
@@ -411,6 +415,7 @@ def main():
 
     rays_per_step = V * H * W
     value = rays_per_step * args.steps / elapsed
+    t_wall["timed"] = time.perf_counter()
 
     # ---- per-kernel accounting (this rank's launches) ------------------------------
     counts = {r: fp.voxel_count[r] for r in fp.voxel_count}
@@ -544,6 +549,46 @@ def main():
                           if v["resident"] and v["ms"] > 0 else {}))
                for k, v in sorted(fam.items())}
 
+    t_wall["counters"] = time.perf_counter()
+    # ---- BASELINE.json configs[3] on the side (N = 1, default run only) ------------------------
+    # The headline is config 2; config 4 (9 views, 128 planes, 256^3, M = 768) gets ONE figure in
+    # the same line so that a driver-run record of it exists: a fresh driver, 5 untimed passes
+    # (plan, work list, the scatter's tile shape), 5 timed ones.  Outside the timed region above.
+    other_configs = None
+    if world == 1 and args.config == "config2" and args.also_config4 and args.schedule == "resident":
+        try:
+            c4 = CONFIGS["config4"]
+            scene4, bank4 = make_synthetic_scene(H=c4["H"], W=c4["W"], n_views=c4["views"], F=c4["F"],
+                                                 padding=c4["padding"], focal=1.5 * c4["H"], seed=1234)
+            gp4 = GenerationParameters(depth_planes=c4["D"], neighbors=c4["views"] - 1,
+                                       grid_shape=np.array(c4["grid"], np.int32),
+                                       max_number_of_marched_voxels=c4["M"], padding=c4["padding"],
+                                       gamma_mrf=0.05)
+            fp._plan = None                 # config 2's 7 GB back to the allocator first
+            fp4 = get_forward_pass_factory("raynet")(bank4, gp4, "sample_in_bbox",
+                                                     (c4["H"], c4["W"]), 0)
+
+            def step4():
+                for _ in fp4.forward_pass(scene4, (0, c4["views"], 1)):
+                    pass
+            for _ in range(5):
+                step4()
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(5):
+                step4()
+            torch.cuda.synchronize()
+            ms4 = (time.perf_counter() - t4) / 5 * 1e3
+            rays4 = c4["views"] * c4["H"] * c4["W"]
+            other_configs = {"config4": {"workload": c4["workload"], "ms_per_step": round(ms4, 3),
+                                         "rays_per_s": round(rays4 / ms4 * 1e3, 1), "steps": 5,
+                                         "rays_per_step": rays4}}
+            del fp4, scene4, bank4
+            torch.cuda.empty_cache()
+        except Exception as e:              # (never at the cost of the headline)
+            other_configs = {"config4": {"error": repr(e)[:200]}}
+
+    t_wall["config4"] = time.perf_counter()
     # ---- CPU baseline, two legs on bounded ray samples drawn from ALL reference images -------
     #  port              the C oracle's fused K1 / K2 (whole path, OpenMP over rays, all cores)
     #  numpy_restatement oracle/cpu_reference.py = the reference's own CPU implementation
@@ -709,6 +754,12 @@ def main():
             "path_roofline": path_roofline,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "other_configs": other_configs,
+            "wall_s": {"imports_scene": round(t_wall["scene"] - t_wall["start"], 1),
+                       "warmup_breakdown_timed": round(t_wall["timed"] - t_wall["scene"], 1),
+                       "counter_passes": round(t_wall["counters"] - t_wall["timed"], 1),
+                       "config4": round(t_wall["config4"] - t_wall["counters"], 1),
+                       "cpu_baseline": round(time.perf_counter() - t_wall["config4"], 1)},
             "kernels": kernels,
             "ranks": ranks_report,
             "step_capture": {"captured": bool(fp.captured), "extra_warmup_steps": extra_warmup,

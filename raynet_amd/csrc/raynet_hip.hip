@@ -20,6 +20,17 @@ constexpr int BOX_PROBE_LAUNCHES = 12;   // scatter launches after a reset whose
 #define RN_RAY_BLOCK 256
 #endif
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+// The plane sweep's own workgroup size (A/B knob, round 5).  The hardware deals consecutive
+// workgroups to different CUs, so only a workgroup's own rays share a CU's L1, and the kernel runs
+// at the rate its L1s get lines from the L2 -- yet more rays per workgroup do not pay: 384 / 512 /
+// 768 / 1024 threads are 22 / 7 / 13 / 36 % slower than 256 at config 2 and 14 / 2 / 14 / 10 % at
+// config 4 (profiles/r05_exp_sweep_block.txt; a first run that seemed to gain 11 % had silently
+// dropped the folded first BP iteration, whose LDS rows no longer fitted).
+#ifndef RN_SWEEP_BLOCK
+#define RN_SWEEP_BLOCK 256
+#endif
+constexpr int SWEEP_BLOCK = RN_SWEEP_BLOCK;
+constexpr int SWEEP_WAVES = SWEEP_BLOCK / WAVE;
 constexpr int NXCD = 8;
 
 // XCD-aware remap: the dispatcher is observed to place block b on XCD b % 8; give
@@ -35,8 +46,13 @@ constexpr int NXCD = 8;
 // became non-temporal; re-measured after that, chunks of 256 - 1024 rays -- one to four 16 x 16
 // pixel tiles -- are 1.5 % faster at config 2 and 6.5 % at config 4, 64 rays are slower, 16384
 // much slower.)
+#ifdef RN_SWEEP_BLOCK
+#define RN_SWEEP_BLOCK_OR_DEFAULT RN_SWEEP_BLOCK
+#else
+#define RN_SWEEP_BLOCK_OR_DEFAULT 256
+#endif
 #ifndef RN_XCD_CHUNK_SWEEP
-#define RN_XCD_CHUNK_SWEEP 512
+#define RN_XCD_CHUNK_SWEEP (2048 * 64 / RN_SWEEP_BLOCK_OR_DEFAULT)      /* workgroups: 2048 rays */
 #endif
 #ifndef RN_XCD_CHUNK_BP
 #define RN_XCD_CHUNK_BP 256
@@ -349,8 +365,9 @@ inline int fill_blocks(int64_t n) {
 }
 inline size_t sweep_lds(const Params &p, int rows = 1) {
     return sizeof(float) * ((size_t)((p.gx + p.gy + p.gz + 3) & ~3) + (size_t)((p.D + 4) & ~3) +
-                            (size_t)WAVES_PER_BLOCK * (p.D + (size_t)rows * p.M));
+                            (size_t)SWEEP_WAVES * (p.D + (size_t)rows * p.M));
 }
+inline int sweep_blocks(int n) { return (n + SWEEP_WAVES - 1) / SWEEP_WAVES; }
 
 // floats of one resident (bricked) accumulator: every axis padded to a multiple of 4
 inline int64_t acc_floats(const rn_ctx *ctx) {
@@ -387,9 +404,12 @@ struct SweepArgs {
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
 void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
     ProfScope prof(ctx, RN_K_SWEEP_MAP, a.n * a.n_images, st);
+    const size_t lds = sweep_lds(ctx->p, MAPMODE == 3 ? 3 : 1);
+    if (lds > 64 * 1024)        // (gfx950 has 160 KB per CU; beyond 64 KB a kernel has to say so)
+        (void)hipFuncSetAttribute((const void *)k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>),
-                       dim3(ray_blocks(a.n), a.n_images), dim3(BLOCK),
-                       sweep_lds(ctx->p, MAPMODE == 3 ? 3 : 1), st,
+                       dim3(sweep_blocks(a.n), a.n_images), dim3(SWEEP_BLOCK), lds, st,
                        ctx->p, a.n, a.ray_idxs, a.fv, a.P, a.P_inv, a.cc, a.starts, a.ends, a.S_in,
                        ctx->axes, a.vox, a.rvc, a.S_planes, a.S_voxel, a.depth_from_planes,
                        a.points, a.order, a.fv_table, a.cam_stride, a.rows_per_image, a.seg,
@@ -1209,7 +1229,7 @@ namespace {
 // LDS a workgroup of the plane sweep may take and still leave room for RN_SWEEP_MIN_WAVES
 // wavefronts per SIMD (4 per workgroup, 160 KB per CU)
 inline bool fold_fits(const Params &p) {
-    return sweep_lds(p, 3) <= (size_t)160 * 1024 / ((RN_SWEEP_MIN_WAVES * 4 + 3) / 4);
+    return sweep_lds(p, 3) <= (size_t)160 * 1024 / ((RN_SWEEP_MIN_WAVES * 4 + SWEEP_WAVES - 1) / SWEEP_WAVES);
 }
 }  // namespace
 
@@ -1288,7 +1308,7 @@ static int scene_prepare_all_impl(rn_ctx *ctx, int32_t n_images, int32_t n, int6
         a.rows_per_image = rows_per_image;
         a.n_images = ng;
         a.seg = ray_segments ? ray_segments + row0 * 8 : nullptr;
-        a.xcd_chunk = sweep_xcd_chunk / WAVES_PER_BLOCK;
+        a.xcd_chunk = sweep_xcd_chunk / SWEEP_WAVES;
         if (msgs_fold) {
             a.msgs_out = msgs_fold + row0 * M;
             a.prior = o_first;

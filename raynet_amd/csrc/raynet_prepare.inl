@@ -359,7 +359,7 @@ __device__ __forceinline__ void first_sweep_messages(int count, int lane, float 
 }
 
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
-__global__ __launch_bounds__(BLOCK, (SIM == 2 && MAPMODE >= 2 && NV >= 5 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
+__global__ __launch_bounds__(SWEEP_BLOCK, (SIM == 2 && MAPMODE >= 2 && NV >= 5 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
 void k_sweep_map(
     Params p, int n, const int32_t *__restrict__ ray_idxs, FeatureViews fv,
     const float *__restrict__ P, const float *__restrict__ P_inv, const float *__restrict__ cc,
@@ -374,8 +374,8 @@ void k_sweep_map(
     // MAPMODE 3 stands in for the first k_bp launch of a pass, including what that launch clears
     // on the side: the partial accumulator the first scatter adds into (see k_bp)
     if (MAPMODE == 3 && zero_buf && blockIdx.y == 0) {
-        const int nw = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
-        const int w = blockIdx.x * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6);
+        const int nw = (n + SWEEP_WAVES - 1) / SWEEP_WAVES * SWEEP_WAVES;
+        const int w = blockIdx.x * SWEEP_WAVES + (int)(threadIdx.x >> 6);
         for (int i = w * WAVE + (int)(threadIdx.x & (WAVE - 1)); i < zero_count4; i += nw * WAVE)
             zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -400,14 +400,14 @@ void k_sweep_map(
     float *Sl = pos + ((p.D + 4) & ~3) + wid * (p.D + (MAPMODE == 3 ? 3 : 1) * p.M);
     float *vals = Sl + p.D;
     if (MAPMODE != 0) {
-        for (int i = threadIdx.x; i < naxes; i += BLOCK) axes[i] = axes_g[i];
+        for (int i = threadIdx.x; i < naxes; i += SWEEP_BLOCK) axes[i] = axes_g[i];
         // the very expression the walk evaluates (planes_voxels_mapping.cu:60-67), once per plane
         if (RESIDENT)
-            for (int i = threadIdx.x; i <= p.D; i += BLOCK) pos[i] = 0.0f + i * p.plane_step;
+            for (int i = threadIdx.x; i <= p.D; i += SWEEP_BLOCK) pos[i] = 0.0f + i * p.plane_step;
         __syncthreads();
     }
     int lane;
-    int r = ray_of_wave<BLOCK, RN_XCD_CHUNK_SWEEP>(n, lane, xcd_chunk);
+    int r = ray_of_wave<SWEEP_BLOCK, RN_XCD_CHUNK_SWEEP>(n, lane, xcd_chunk);
     if (r < 0) return;
     RN_PHASE_DECL;
     RN_PHASE_MARK(0);                      // (clock read only)

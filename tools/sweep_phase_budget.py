@@ -55,7 +55,7 @@ def counters(lib, names, config, tag):
     for i in range(0, len(names), 4):            # a few counters per pass
         sub = names[i:i + 4]
         subprocess.run("rm -rf %s; cd /tmp && rocprofv3 --pmc %s --output-format csv -d %s -o p -- "
-                       "python %s/bench.py --config %s --pmc off --no-cpu-baseline --steps 2 > /dev/null 2>&1"
+                       "python %s/bench.py --config %s --pmc off --no-cpu-baseline --no-config4 --steps 2 > /dev/null 2>&1"
                        % (out, " ".join(sub), out, REPO, config), shell=True, env=env, check=False)
         for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(f)):
