@@ -58,6 +58,11 @@ SHAPES = {
                  grid=[32, 32, 32]),
     "aniso": dict(M=64, D=32, N=4, F=16, H=20, W=28, padding=11,
                   bbox=[-1.5, -1, -0.5, 1.5, 1, 0.75], grid=[24, 16, 10]),
+    # BASELINE.json configs[0]: the mock Restrepo scene's box -- its -0.7 is NOT a float32 value, so the
+    # decimal text the reference substitutes ("-0.7", a double literal) and the float32 the caller
+    # holds differ in the 9th digit (tests/test_reference_kernels.py: what that moves)
+    "config1": dict(M=96, D=16, N=2, F=32, H=36, W=64, padding=11, bbox=[-5, -5, -0.7, 5, 5, 1.5],
+                    grid=[32, 32, 32]),
     "config2": dict(M=384, D=64, N=5, F=32, H=480, W=640, padding=11, bbox=[-1, -1, -1, 1, 1, 1],
                     grid=[128, 128, 128]),
     "config4": dict(M=768, D=128, N=9, F=32, H=480, W=640, padding=11, bbox=[-1, -1, -1, 1, 1, 1],

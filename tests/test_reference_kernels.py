@@ -320,3 +320,32 @@ def test_hip_sweep_vs_live_reference_kernel_full_image(torch):
         moved = (S_fma - S_ref).abs().max(1).values > 1e-5
         assert float(moved.float().mean()) <= 0.005
         assert float((S - S_fma).abs().max(1).values[~moved].max()) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_box_given_as_decimal_text_moves_only_last_bits(torch):
+    """The reference bakes the bounding box into its kernels as DECIMAL TEXT (raynet_fp.py:241-246:
+    str(np.float32(-0.7)) = "-0.7", read by the compiler as the double -0.7 -- with NumPy < 1.14 it
+    would have been "-0.69999999"), the library holds the caller's float32 (-0.699999988).  On the
+    mock Restrepo box of BASELINE.json configs[0], whose -0.7 is no float32 value, over every ray of
+    the twelve cameras: ray end points differ in their last bits on a few rays, the two traversal
+    flavours (CUDA: double-promoted literals; Cython, the one followed: SURVEY Q9) give the same
+    lists on the same end points, and the plane-sweep columns of the fused a1 + a2 kernel agree to
+    rounding.  (tools/ref_cu_bbox_census.py, profiles/r05_ref_cu_bbox_census.json: 14 starts and
+    392 last points of 27,648 rays, <= 2.2e-6.)"""
+    import ref_cu
+    if not ref_cu.available() or "config1" not in ref_cu.manifest()["shapes"]:
+        pytest.skip("oracle/_ref/raynet_ref_config1_*.co not built (oracle/build_ref_cu.py needs /root/reference)")
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "ref_cu_bbox_census.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    c = json.load(open(os.path.join(REPO, "gpurun_out", "r05_ref_cu_bbox_census.json")))
+    assert c["rays"] == 12 * 36 * 64 and c["live_rays"] > 0.9 * c["rays"]
+    assert c["start_differs"] <= 0.005 * c["rays"] and c["end_differs"] <= 0.05 * c["rays"]
+    assert c["max_endpoint_diff"] <= 4e-6          # a few ulp of coordinates up to 5
+    assert c["lists_differ_same_endpoints"] == 0
+    assert c["sweep_rays_gt_1e5"] == 0 and c["sweep_max"] <= 1e-6
