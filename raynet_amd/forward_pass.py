@@ -105,21 +105,6 @@ def sweep_direction(H, W, images):
     return "rows" if dx > dy else "cols"
 
 
-def row_major_order(ray_idxs, H, W):
-    """int32 permutation that visits the rays in row-major pixel order
-    (pixel x = idx / H, y = idx % H, sampling_schemes.cu:5-8)."""
-    r = ray_idxs.to(torch.int64)
-    return torch.argsort((r % H) * W + (r // H)).to(torch.int32)
-
-
-def sweep_order(ray_idxs, H, W, images):
-    """Schedule of the plane sweep (see sweep_direction): a permutation, or None for the
-    natural column-major order of ray indices."""
-    if sweep_direction(H, W, images) == "rows":
-        return row_major_order(ray_idxs, H, W)
-    return None
-
-
 def tile_order(ray_idxs, H, W, tile_x, tile_y, along_rows=False):
     """The ray list (idx = x*H + y, sampling_schemes.cu:5-8) re-ordered into tile_x x tile_y
     pixel patches: consecutive rows of the per-ray buffers are then neighbouring rays in BOTH
@@ -349,10 +334,6 @@ class RayNetForwardPass(ForwardPass):
     deterministic = property(lambda self: self.options.deterministic,
                              lambda self, v: setattr(self, "options",
                                                      self.options.replace(deterministic=bool(v))))
-    sweep_reorder = property(lambda self: self.options.sweep_reorder,
-                             lambda self, v: setattr(self, "options",
-                                                     self.options.replace(sweep_reorder=bool(v))))
-
     @property
     def accumulator(self):
         """[gx][gy][gz] log-odds accumulator of the last pass (mrf_bp.cu:3-10 layout).  The
@@ -437,8 +418,7 @@ class RayNetForwardPass(ForwardPass):
         # the first reference image: one list serves the whole scene)
         epipolar_rows = bool(refs) and sweep_direction(
             H, W, [scene.get_image(v) for v in views_of[refs[0]]]) == "rows"
-        along_rows = patch_rows and bool(refs) and (
-            opt.tile_along == "rows" or (opt.tile_along == "auto" and epipolar_rows))
+        along_rows = patch_rows and epipolar_rows
         lists, shared = {}, None
         for r in refs:
             if self._filter_out_rays:
@@ -632,7 +612,7 @@ class RayNetForwardPass(ForwardPass):
         plan = dict(key=key, ptrs=ptrs, scene=scene, cams=cams, prior=self._prior(), dirty=False,
                     cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
                     balance=balance, shards=shards, npad=npad, shared=shared,
-                    patch_rows=patch_rows, orders={}, stitch=None, fast=None, direct=False,
+                    patch_rows=patch_rows, fast=None, direct=False,
                     along_rows=self._along_rows,
                     table=torch.tensor(ptrs, dtype=torch.int64).to(dev) if V else None)
         self._plan_buffers(ctx, plan, refs, old_bytes)
@@ -657,13 +637,6 @@ class RayNetForwardPass(ForwardPass):
         if dist is not None and not (dev.type == "cuda" and (H * W) % 4 == 0 and
                                      hasattr(ctx, "stitch_rows")):
             fast_ok = False     # the owners' maps are put together by rn_stitch_rows (float4 stores)
-        order = None
-        if fast_ok and not patch_rows and opt.sweep_reorder:
-            modes = {sweep_direction(H, W, [scene.get_image(v) for v in views_of[r]]) for r in refs}
-            if modes == {"rows"}:
-                order = row_major_order(shards[0][0], H, W) if shards[0][0].numel() else None
-            elif "rows" in modes:
-                fast_ok = False           # per-image schedules: the launch-by-launch path
         if dist is not None and world > 1 and hasattr(ctx, "scene_run"):
             # the two paths exchange differently (per-image all-gathers / one): every rank must
             # take the same one, and a rank's HBM budget may have decided otherwise
@@ -673,15 +646,14 @@ class RayNetForwardPass(ForwardPass):
         if fast_ok:
             # no process group: the depth sweeps write the maps in pixel order themselves
             # (rn_scene_plan.depth_image) -- no reordering pass between sweep and copy.  (With
-            # a group the rows are exchanged first, _emit_image.)
-            plan["direct"] = dist is None and dev.type == "cuda" and opt.direct_maps
+            # a group the rows are exchanged first, _epilogue_buffers.)
+            plan["direct"] = dist is None
             if plan["direct"]:
                 plan["maps_dev"] = torch.zeros((V, H * W), dtype=torch.float32, device=dev)
             plan["fast"] = ctx.scene_plan(
                 V, npad, shards[0][0], plan["table"], cam_dev, plan["vox"], plan["rvc"],
                 plan["Sr"], plan["msgs"], plan["acc_a"], plan["acc_b"], plan["depth"],
                 plan["prior"], patch_rows, acc_fixed=plan["acc_part"] if plan["fixed"] else None,
-                order=order,
                 **({"depth_image": plan["maps_dev"]} if plan["direct"] else {}))
         if not self._filter_out_rays:
             self._plan = plan
@@ -751,7 +723,6 @@ class RayNetForwardPass(ForwardPass):
         plan["wait_ev"] = [None] * V
         if cuda:
             plan["ev_ready"] = [torch.cuda.Event() for _ in range(V)]
-            plan["ev_stitch"] = [torch.cuda.Event() for _ in range(V)]
             plan["ev_done"] = [torch.cuda.Event() for _ in range(V)]
             plan["ev_all"] = torch.cuda.Event()
             if self._side_stream is None:
@@ -759,9 +730,6 @@ class RayNetForwardPass(ForwardPass):
         npad, lists, bounds = plan["npad"], plan["lists"], plan["bounds"]
         plan["owners"] = [map_owner(k, V, world) for k in range(V)] if collective else None
         if not collective:
-            # rows -> pixels: one index per image (rays that were filtered out stay 0)
-            plan["pix"] = [lists[r].long() for r in refs] if (
-                plan["patch_rows"] or self._filter_out_rays) else None
             return
         # With a process group (the plan path then requires rn_stitch_rows, _build_plan): image
         # k's map is assembled on ONE rank.  ONE depth launch over all of a rank's rows, ONE
@@ -797,28 +765,6 @@ class RayNetForwardPass(ForwardPass):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.trace.append((name, begin, ev))
-
-    def _emit_image(self, plan, k, st, host_set):
-        """One GPU, no process group: image k's depth rows (just enqueued on the current stream)
-        -> pixel order -> pinned host memory, on side streams: under the depth sweep of image
-        k + 1 (the reorder on the first side stream, the copy to the host on the second)."""
-        host = host_set[k]
-        rows = plan["depth"][st["row0"]:st["row0"] + st["n"]]
-        side, copy = self._side_stream, self._copy_stream
-        plan["ev_ready"][k].record()
-        with torch.cuda.stream(side):
-            side.wait_event(plan["ev_ready"][k])
-            if plan["pix"] is not None:
-                plan["maps_dev"][k].index_copy_(0, plan["pix"][k], rows)
-                src = plan["maps_dev"][k]
-            else:
-                src = rows
-            plan["ev_stitch"][k].record()
-        with torch.cuda.stream(copy):
-            copy.wait_event(plan["ev_stitch"][k])
-            host.copy_(src, non_blocking=True)
-            plan["ev_done"][k].record()
-        plan["wait_ev"][k] = plan["ev_done"][k]
 
     def _emit_direct(self, plan, groups, host_set):
         """The maps of the image groups [a, b) -- written in pixel order by their depth launches,
@@ -886,13 +832,13 @@ class RayNetForwardPass(ForwardPass):
             self._exchange(plan, ctx, dist, world, it)
         final = plan["acc_b" if (T - 1) & 1 else "acc_a"]
         self._acc_flat, self._acc_bias = final, (0.0 if fixed else plan["prior"])
-        per_image = plan["per_image"]
         V = len(refs)
         if plan["direct"]:
-            # every depth launch first (the GPU never waits for the host between them), then
-            # the copies: all images but the last in ONE launch and ONE copy, under the last's
-            head = V >= 3 and self.options.depth_head
-            groups = [(0, V - 1), (V - 1, V)] if head else [(k, k + 1) for k in range(V)]
+            # one GPU, no process group: the depth launches write the maps in pixel order
+            # themselves (rn_scene_plan.depth_image).  Every launch first (the GPU never waits for
+            # the host between them), then the copies: all images but the last in ONE launch and
+            # ONE copy, under the last image's launch
+            groups = [(0, V - 1), (V - 1, V)] if V >= 3 else [(k, k + 1) for k in range(V)]
             for a, b in groups:
                 if b - a > 1:
                     ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, a | ((b - a) << 16))
@@ -900,7 +846,7 @@ class RayNetForwardPass(ForwardPass):
                     ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, a)
                 plan["ev_ready"][a].record()
             self._emit_direct(plan, groups, host_set)
-        elif dist is not None:
+        else:
             # sharded rays, owner-only maps (_epilogue_buffers): ONE depth launch over all of
             # this rank's rows, ONE all-gather of the ranks' rows, ONE stitch launch on an owner
             rows = plan["rows"]
@@ -921,18 +867,6 @@ class RayNetForwardPass(ForwardPass):
                 plan["ev_done"][0].record()
             for k in range(V):
                 plan["wait_ev"][k] = plan["ev_done"][0]
-        elif V >= 3 and self.options.depth_head:
-            # one GPU: all images but the last decoded by ONE launch (no launch tails between
-            # them), the last on its own -- long enough for the others' maps to leave under it.
-            ctx.scene_run(fast, _lib.RN_RUN_DEPTH_RANGE, T, 0 | ((V - 1) << 16))
-            for j in range(V - 1):
-                self._emit_image(plan, j, per_image[refs[j]], host_set)
-            ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, V - 1)
-            self._emit_image(plan, V - 1, per_image[refs[V - 1]], host_set)
-        else:
-            for k, r in enumerate(refs):
-                ctx.scene_run(fast, _lib.RN_RUN_DEPTH, T, k)
-                self._emit_image(plan, k, per_image[r], host_set)
         if captured:
             cur = torch.cuda.current_stream(ctx.device)
             cur.wait_stream(self._side_stream)
@@ -1091,18 +1025,12 @@ class RayNetForwardPass(ForwardPass):
                 self.messages.put(r, st["msgs"], st["rvc"])
                 self.voxel_count[r] = st["rvc"]
             owners = plan["owners"]
-            spin = self.options.spin_wait
             for k, r in enumerate(refs):
                 self.ref_idx = r
                 if owners is not None and owners[k] != rank:
                     yield None             # another rank assembles this image (map_owner)
                     continue
-                ev = plan["wait_ev"][k]
-                if spin:
-                    while not ev.query():
-                        pass
-                else:
-                    ev.synchronize()
+                plan["wait_ev"][k].synchronize()
                 a = self._lease(mset, k) if leased else host_set[k].numpy().copy()
                 yield a.reshape(W, H).T
                 del a
@@ -1139,22 +1067,8 @@ class RayNetForwardPass(ForwardPass):
             msgs_all.zero_()
         per_image = plan["per_image"]
 
-        def order_for(ridx_slice, lo_i, hi_i, images):
-            # patch rows are already compact in both image directions (measured: the
-            # row-major schedule gains nothing on top of them)
-            if patch_rows or not self.sweep_reorder or sweep_direction(H, W, images) != "rows":
-                return None
-            okey = (lo_i, hi_i)
-            if self._filter_out_rays or okey not in plan["orders"]:
-                plan["orders"][okey] = row_major_order(ridx_slice, H, W)
-            return plan["orders"][okey]
-
         whole = plan["shared"] is not None and not self.rays_batch and V > 0 and \
             hasattr(ctx, "scene_prepare_all")
-        if whole and not patch_rows and self.sweep_reorder:
-            # (patch rows take no sweep order at all, see order_for)
-            modes = {sweep_direction(H, W, [scene.get_image(v) for v in views_of[r]]) for r in refs}
-            whole = len(modes) == 1
 
         def prepare(group):
             """K1 prefix (traversal, plane sweep, mapping, clip + renormalise) of the group's
@@ -1162,27 +1076,24 @@ class RayNetForwardPass(ForwardPass):
             g0, g1 = group[0], group[-1] + 1
             if whole:
                 # every image traverses / sweeps the same ray list: two launches for the group
-                ridx, lo, hi, total = shards[g0]
-                order = order_for(ridx, lo, hi, [scene.get_image(v) for v in views_of[refs[g0]]])
+                ridx = shards[g0][0]
                 ctx.scene_prepare_all(g1 - g0, npad, ridx, plan["table"][g0:g1], cam_dev[g0:g1],
                                       vox_g[:(g1 - g0) * npad], rvc_all[g0 * npad:g1 * npad],
-                                      Sr_g[:(g1 - g0) * npad], order=order)
+                                      Sr_g[:(g1 - g0) * npad])
                 return
             for j, k in enumerate(group):
                 r = refs[k]
                 st = per_image[r]
-                ridx, lo, n = st["ridx"], st["lo"], st["n"]
+                ridx, n = st["ridx"], st["n"]
                 views = views_of[r]
-                images = [scene.get_image(v) for v in views]
                 P = cam_dev[k, :12 * N]
                 P_inv = cam_dev[k, 12 * N:12 * N + 12]
                 B = self.rays_batch if self.rays_batch else max(n, 1)
                 vox_k, Sr_k = vox_g[j * npad:j * npad + n], Sr_g[j * npad:j * npad + n]
                 for i in range(0, n, B):
-                    order = order_for(ridx[i:i + B], lo + i, min(lo + i + B, st["hi"]), images)
                     ctx.scene_prepare(ridx[i:i + B], [bank[v] for v in views], P, P_inv,
                                       st["center"], vox_k[i:i + B], st["rvc"][i:i + B],
-                                      Sr_k[i:i + B], order=order)
+                                      Sr_k[i:i + B])
 
         # K1 prefix once per reference image when every image's columns fit in HBM (they do at
         # every configuration of BASELINE.json); otherwise group by group inside every sweep.

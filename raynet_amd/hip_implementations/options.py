@@ -32,16 +32,11 @@ def _flag(text):
 class PathOptions:
     # ---- row layout and schedule of the resident buffers (host side) -------------------
     ray_tile: Optional[Tuple[int, int]] = (16, 16)   # pixel patch per 256 rows; None: ray-index order
-    tile_along: str = "auto"          # patches enumerated along image "rows" / "cols"; "auto": by the epipoles
-    sweep_reorder: bool = True        # epipolar row-major schedule of the plane sweep for ray-index rows
     scatter_items: bool = True        # the box scatter takes a work list built from the rays' voxel
     #                                   counts (a tile's live chunks in pieces, longest first) from a
     #                                   plan's second pass on, instead of tiles x a fixed split
     slab_boxes: bool = True           # the scatters merge the traversal's slab boxes instead of scanning
     plan_path: bool = True            # one C call per phase of a pass (rn_scene_run) when the pass qualifies
-    depth_head: bool = True           # one GPU: all images but the last decoded by one launch
-    direct_maps: bool = True          # no process group: the depth sweeps write pixel-order maps
-    spin_wait: bool = False           # poll the maps' events instead of blocking on them
     capture: str = "auto"             # the plan path's whole step (phases, exchanges, epilogue) as ONE
     #                                   captured HIP graph per plan, replayed per pass -- no interpreter and
     #                                   no launch overhead between the launches: "on", "off", or "auto" =
@@ -74,14 +69,9 @@ class PathOptions:
     # environment variable -> (field, parser); overrides only
     ENV = {
         "RAYNET_RAY_TILE": ("ray_tile", _tile),
-        "RAYNET_TILE_ALONG": ("tile_along", str),
-        "RAYNET_SWEEP_REORDER": ("sweep_reorder", _flag),
         "RAYNET_SLAB_BOXES": ("slab_boxes", _flag),
         "RAYNET_SCATTER_ITEMS": ("scatter_items", _flag),
         "RAYNET_PLAN_PATH": ("plan_path", _flag),
-        "RAYNET_DEPTH_HEAD": ("depth_head", _flag),
-        "RAYNET_DIRECT_MAPS": ("direct_maps", _flag),
-        "RAYNET_SPIN_WAIT": ("spin_wait", _flag),
         "RAYNET_CAPTURE": ("capture", lambda t: {"0": "off", "1": "on"}.get(str(t).strip(), str(t).strip())),
         "RAYNET_MAPS": ("maps", str),
         "RAYNET_RESIDENT_GB": ("resident_gb", float),
@@ -99,7 +89,6 @@ class PathOptions:
     def __post_init__(self):
         if self.ray_tile is not None:
             self.ray_tile = (int(self.ray_tile[0]), int(self.ray_tile[1]))
-        assert self.tile_along in ("auto", "rows", "cols"), self.tile_along
         assert self.shard in ("voxels", "rays"), self.shard
         assert self.exchange in ("allreduce", "reduce_scatter"), self.exchange
         assert self.scatter_mode in (-1, 0, 2) and self.box_level in (0, 1, 2)
@@ -143,7 +132,7 @@ class PathOptions:
         if k is None:
             # (what a plan's buffers and tables depend on: not how its passes are issued / awaited)
             k = tuple(sorted((n, v) for n, v in self.as_dict().items()
-                             if n not in ("capture", "spin_wait")))
+                             if n != "capture"))
             object.__setattr__(self, "_key", k)
         return k
 

@@ -506,9 +506,9 @@ def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
 def test_pixel_order_maps_straight_from_the_depth_sweep(torch):
     """Without a process group the depth launches write the maps in ray-index (pixel) order
     themselves (rn_scene_plan.depth_image) and a group of images leaves in one copy: the same
-    bits as the row-order maps re-ordered behind the sweep (direct_maps=False), for image counts
-    with and without the head launch, rows that do not fill their last tile (45 x 61 rays),
-    ray-index rows, and a sub-range of the images."""
+    bits as the launch-by-launch path's row-order maps re-ordered behind the sweep, for image
+    counts with and without the head launch, rows that do not fill their last tile (45 x 61
+    rays), ray-index rows, and a sub-range of the images."""
     from raynet_amd.forward_pass import get_forward_pass_factory
     from raynet_amd.hip_implementations.options import PathOptions
     from raynet_amd.synthetic import make_synthetic_scene
@@ -520,10 +520,10 @@ def test_pixel_order_maps_straight_from_the_depth_sweep(torch):
         out = {}
         for direct in (True, False):
             fp = cls(bank, gp, "sample_in_bbox", (H, W), 0,
-                     options=PathOptions(deterministic=True, direct_maps=direct, ray_tile=tile))
+                     options=PathOptions(deterministic=True, plan_path=direct, ray_tile=tile))
             out[direct] = np.stack([m.copy() for m in fp.forward_pass(scene, rng)])
-            assert fp._plan["fast"] is not None and fp._plan["direct"] == direct
-            again = np.stack(list(fp.forward_pass(scene, rng)))         # the other host slot
+            assert (fp._plan["fast"] is not None) == direct and fp._plan["direct"] == direct
+            again = np.stack(list(fp.forward_pass(scene, rng)))
             assert np.array_equal(again, out[direct])
         assert out[True].shape == (len(range(*rng)), H, W)
         assert np.array_equal(out[True], out[False]), (rng, tile)
