@@ -113,6 +113,7 @@ def main():
         "non_finite_voxels_oracle": int((~np.isfinite(acc_o)).sum()),
         "non_finite_voxels_kernel": int((~np.isfinite(acc_ref)).sum()),
         "same_voxels_non_finite": bool(np.array_equal(np.isfinite(acc_o), np.isfinite(acc_ref))),
+        "non_finite_in_both": int((~np.isfinite(acc_o) & ~np.isfinite(acc_ref)).sum()),
         "max_abs_accumulator_diff_where_both_finite": float(np.abs(acc_o - acc_ref)[both].max()),
         "voxels_beyond_1e-2": int((np.abs(acc_o - acc_ref)[both] > 1e-2).sum()),
         "non_finite_messages_oracle": int(sum((~np.isfinite(st["msgs"])).sum() for st in host))}
