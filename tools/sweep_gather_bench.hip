@@ -44,10 +44,12 @@ template <int NV>
 __global__ __launch_bounds__(256) void k_ray_coop(int n, int D, const int32_t *__restrict__ offs,
                                                   const int32_t *__restrict__ live, Views fv,
                                                   float *out, int chunk) {
+    extern __shared__ float lds_cap[];                   // (only there to cap occupancy: --lds)
     const int lane = threadIdx.x & 63;
     const int b = xcd_block_rt(blockIdx.x, (n + 3) / 4, chunk);
     const int r = __builtin_amdgcn_readfirstlane(b * 4 + (int)(threadIdx.x >> 6));
     if (r >= n || live[r] <= 1) return;
+    if (n < 0) lds_cap[lane] = 0.f;
     const int sub = lane >> 3, part = lane & 7;
     float acc = 0.f;
     for (int base = 0; base < D; base += WAVE) {
@@ -144,7 +146,13 @@ static int launch(int variant, int n, int D, const int32_t *offs, const int32_t 
                            out, chunk);                                                           \
     }
     switch (variant) {
-        case 0: hipLaunchKernelGGL(k_ray_coop<NV>, dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
+        case 0: {
+            auto k = k_ray_coop<NV>;
+            if (lds_bytes > 65536)
+                (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            hipLaunchKernelGGL(k, dim3((n + 3) / 4), dim3(256), lds_bytes, st, n, D, offs, live, fv, out, chunk);
+            break;
+        }
         case 1: hipLaunchKernelGGL(k_ray_lane<NV>, dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
         case 2: TILE(16, 16) break;
         case 3: TILE(8, 16) break;

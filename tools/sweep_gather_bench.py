@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--image", type=int, default=0)
     ap.add_argument("--variants", default="0,1,2,3,4,5,6")
     ap.add_argument("--lds", type=int, default=131072, help="dynamic LDS of the tile kernels (occupancy cap)")
+    ap.add_argument("--ray-lds", type=int, default=0, help="dynamic LDS of the ray-order kernel (occupancy cap)")
     ap.add_argument("--chunk", type=int, default=512, help="workgroups side by side on one XCD (ray order)")
     ap.add_argument("--tile-chunk", type=int, default=8, help="tiles side by side on one XCD")
     ap.add_argument("--once", action="store_true", help="one launch per variant (for counter passes)")
@@ -90,7 +91,7 @@ def main():
 
         def run():
             rc = lib.sgb_run(v, n, N, D, offs.data_ptr(), live.data_ptr(), ptrs, out.data_ptr(), chunk,
-                             args.lds if v >= 2 else 0, stream)
+                             args.lds if v >= 2 else args.ray_lds, stream)
             assert rc == 0, rc
         if args.once:
             run()
