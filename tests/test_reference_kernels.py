@@ -385,3 +385,74 @@ def test_reference_kernels_through_the_reference_schedule_at_full_size(torch):
     lib = rep["library"]
     assert lib["accumulator_finite_everywhere"] and lib["depth_maps_finite"]
     assert rep["depth_maps"]["fraction_beyond_1e-4"] <= 0.01         # observed 0.33 %
+
+
+@pytest.mark.gpu
+def test_hip_chain_vs_live_reference_kernels_full_image(torch):
+    """a3, a4, a5 (first sweep) and a6 over EVERY ray of a config-2 reference image, each library
+    kernel against a live launch of the reference's own on the same inputs: voxel lists and counts
+    bit-exact, mapped columns to 6e-6 relative (the normaliser's summation order), first-sweep messages within the logit conditioning bound,
+    distributions <= 1e-5."""
+    import ref_cu
+    if not ref_cu.available():
+        pytest.skip("oracle/_ref/raynet_ref_*.co not built (oracle/build_ref_cu.py needs /root/reference)")
+    from oracle import oracle
+    from raynet_amd.hip_implementations import get_context
+    from raynet_amd.mrf.mrf_hip import batch_ray_belief_propagation
+    from raynet_amd.planes_voxels_mapping.planes_voxels_mapping_hip import batch_depth_to_voxels_mapping
+    from raynet_amd.ray_marching.ray_tracing_hip import batch_voxel_traversal
+    from raynet_amd.synthetic import make_synthetic_scene
+    shape = ref_cu.manifest()["shapes"]["config2"]
+    M, D, N, F, H, W, pad = (shape[k] for k in ("M", "D", "N", "F", "H", "W", "padding"))
+    bbox, grid = np.asarray(shape["bbox"], np.float32), tuple(shape["grid"])
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=N, F=F, padding=pad, focal=1.5 * H, seed=1234)
+    ctx = get_context(M, D, N, F, H, W, pad, bbox, grid)
+    r = ref_cu.RefCu("config2", "nofma")
+    image, n = 2, H * W
+    views = scene.view_indices_with_neighbors(image, N - 1)
+    feats = bank.stacked(views)
+    P = ctx.dev(np.array([scene.get_image(v).camera.P for v in views], np.float32))
+    cam = scene.get_image(image).camera
+    s = torch.zeros((n, 3), device="cuda")
+    e = torch.zeros((n, 3), device="cuda")
+    ctx.sample_rays(torch.arange(n, dtype=torch.int32, device="cuda"), ctx.dev(cam.P_pinv.astype(np.float32)),
+                    ctx.dev(cam.center.ravel().astype(np.float32)), s, e)
+    # a3
+    rvi_r, rvc_r = r.traversal(s, e)
+    rvi = torch.zeros((n, M, 3), dtype=torch.int32, device="cuda")
+    rvc = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    batch_voxel_traversal(M, bbox, np.array(grid, np.int32))(s, e, rvi, rvc)
+    assert torch.equal(rvc, rvc_r) and torch.equal(rvi, rvi_r)
+    assert int(rvc.max()) > 200 and int((rvc == 0).sum()) > 0          # long rays, and rays that miss
+    # a4 (on the reference's own column)
+    S = r.similarities(feats, P.reshape(-1), s, e)
+    vg = oracle.voxel_grid_centers(bbox, grid)
+    Sv_r = r.planes_to_voxels(vg, rvi, rvc, s, e, S)
+    Sv = torch.zeros((n, M), device="cuda")
+    batch_depth_to_voxels_mapping(M, D, grid, bbox)(vg, rvi, rvc, s, e, S, Sv)
+    # (the column's normaliser is a sum of up to M terms -- sequential in the kernel, where its
+    # rounding error grows with the count, a wave reduction here: every value of a ray carries the
+    # same relative shift, 2.2e-6 observed on a 254-voxel ray)
+    dmap = (Sv - Sv_r).abs()
+    assert bool((dmap <= 2e-7 + 6e-6 * Sv_r.abs()).all()), float(dmap.max())
+    # a5: the first sweep (accumulator = the prior, messages zero); rays with < 2 voxels send nothing
+    prior = float(np.float32(np.log(0.05) - np.log(0.95)))
+    rvc_bp = torch.where(rvc >= 2, rvc, torch.zeros_like(rvc))
+    acc0 = torch.full(grid, prior, device="cuda")
+    m_r = torch.zeros((n, M), device="cuda")
+    acc_r = torch.full(grid, prior, device="cuda")
+    r.bp_sweep(Sv_r.clone(), rvi, rvc_bp, acc0, m_r, acc_r)
+    bp, de = batch_ray_belief_propagation(M, grid)
+    m_h = torch.zeros((n, M), device="cuda")
+    acc_h = torch.full(grid, prior, device="cuda")
+    bp(Sv_r, rvi, rvc, acc0, m_h, acc_h)
+    assert bool(torch.isfinite(m_r).all())
+    tol = 1e-5 + 8 * 2.0 ** -24 * torch.exp(m_r.abs().clamp(max=17.0))
+    assert bool(((m_h - m_r).abs() <= tol).all()), float(((m_h - m_r).abs() / tol).max())
+    scale = float(acc_r.abs().max())
+    assert float((acc_h - acc_r).abs().max()) <= 2e-5 * scale          # atomics in another order
+    # a6 on the reference's accumulator and messages
+    S_new_r = r.depth_estimation(Sv_r.clone(), rvi, rvc_bp, acc_r, m_r)
+    S_new = torch.zeros((n, M), device="cuda")
+    de(Sv_r, rvi, rvc, acc_r, m_r, S_new)
+    assert float((S_new - S_new_r).abs().max()) <= 1e-5
