@@ -456,3 +456,46 @@ def test_hip_chain_vs_live_reference_kernels_full_image(torch):
     S_new = torch.zeros((n, M), device="cuda")
     de(Sv_r, rvi, rvc, acc_r, m_r, S_new)
     assert float((S_new - S_new_r).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_k10_vs_live_reference_kernel_full_image(torch):
+    """K10, the kernel of the reference's MultiViewCNNForwardPass driver
+    (similarities.py:168-227: a1 + a2 + plane points + first arg-max plane + distance to the
+    camera), over every ray of a config-2 image: columns <= 1e-5, plane points bit-exact, depths
+    equal except where the reference's two best planes are within the columns' tolerance."""
+    import ref_cu
+    if not ref_cu.available():
+        pytest.skip("oracle/_ref/raynet_ref_*.co not built (oracle/build_ref_cu.py needs /root/reference)")
+    from raynet_amd.hip_implementations.similarities import \
+        perform_multi_view_cnn_forward_pass_with_depth_estimation
+    from raynet_amd.synthetic import make_synthetic_scene
+    shape = ref_cu.manifest()["shapes"]["config2"]
+    M, D, N, F, H, W, pad = (shape[k] for k in ("M", "D", "N", "F", "H", "W", "padding"))
+    bbox = np.asarray(shape["bbox"], np.float32)
+    scene, bank = make_synthetic_scene(H=H, W=W, n_views=N, F=F, padding=pad, focal=1.5 * H, seed=1234)
+    image, n = 1, H * W
+    views = scene.view_indices_with_neighbors(image, N - 1)
+    feats = bank.stacked(views)
+    cam = scene.get_image(image).camera
+    r = ref_cu.RefCu("config2", "nofma")
+    ridx = torch.arange(n, dtype=torch.int32, device="cuda")
+    P = r.dev(np.array([scene.get_image(v).camera.P for v in views], np.float32).reshape(-1))
+    P_inv, cc = r.dev(cam.P_pinv.astype(np.float32).reshape(-1)), r.dev(cam.center.ravel().astype(np.float32))
+    S_r = torch.zeros((n, D), device="cuda")
+    pts_r = torch.zeros((n, D, 4), device="cuda")
+    depth_r = torch.zeros((n,), device="cuda")
+    r.launch("batch_multi_view_cnn_forward_pass_with_depth", n, ridx, feats, P, P_inv, cc, S_r, pts_r, depth_r)
+    fp = perform_multi_view_cnn_forward_pass_with_depth_estimation(D, N, F, H, W, pad, bbox, "sample_in_bbox")
+    S = torch.zeros((n, D), device="cuda")
+    pts = torch.zeros((n, D, 4), device="cuda")
+    depth = torch.zeros((n,), device="cuda")
+    fp(ridx, feats, P.reshape(N, 3, 4), P_inv.reshape(4, 3), cc, S, pts, depth)
+    assert float((S - S_r).abs().max()) <= 1e-5
+    assert torch.equal(pts, pts_r)
+    top = torch.topk(S_r, 2, dim=1).values
+    tie = (top[:, 0] - top[:, 1]) <= 2e-5
+    dd = (depth - depth_r).abs()
+    # (1.4 % of this image's rays see noise only: flat columns whose two best planes are that close)
+    assert float(dd[~tie].max()) <= 1e-5 and float(tie.float().mean()) < 0.05
+    assert float((dd <= 1e-5).float().mean()) >= 0.995
