@@ -39,6 +39,50 @@ __device__ __forceinline__ int xcd_block_rt(int b, int nblocks, int chunk) {
 
 __device__ __forceinline__ float sum4(float4v f) { return (f.x + f.y) + (f.z + f.w); }
 
+// one 16-byte load with a cache policy: 0 default, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 sc0 sc1 nt
+template <int POL>
+__device__ __forceinline__ float4v load16(const float *base, unsigned off) {
+    float4v f;
+    if (POL == 0) return *(gptr4)((gptr)base + off);
+    if (POL == 1) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(f) : "v"(off), "s"(base) : "memory");
+    if (POL == 2) asm volatile("global_load_dwordx4 %0, %1, %2 sc0" : "=v"(f) : "v"(off), "s"(base) : "memory");
+    if (POL == 3) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(f) : "v"(off), "s"(base) : "memory");
+    if (POL == 4) asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(f) : "v"(off), "s"(base) : "memory");
+    if (POL == 5) asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1 nt" : "=v"(f) : "v"(off), "s"(base) : "memory");
+    return f;
+}
+
+// the product's order with a cache policy on the gathers (asm loads: waited for once per chunk)
+template <int NV, int POL>
+__global__ __launch_bounds__(256) void k_ray_coop_pol(int n, int D, const int32_t *__restrict__ offs,
+                                                      const int32_t *__restrict__ live, Views fv,
+                                                      float *out, int chunk) {
+    const int lane = threadIdx.x & 63;
+    const int b = xcd_block_rt(blockIdx.x, (n + 3) / 4, chunk);
+    const int r = __builtin_amdgcn_readfirstlane(b * 4 + (int)(threadIdx.x >> 6));
+    if (r >= n || live[r] <= 1) return;
+    const int sub = lane >> 3, part = lane & 7;
+    float acc = 0.f;
+    for (int base = 0; base < D; base += WAVE) {
+        int ob[NV];
+#pragma unroll
+        for (int v = 1; v < NV; v++)
+            ob[v] = offs[((size_t)r * NV + v) * D + min(base + lane, D - 1)] << 7;
+        float4v f[8][NV];
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int v = 1; v < NV; v++)
+                f[t][v] = load16<POL>(fv.v[v], (unsigned)__shfl(ob[v], t * 8 + sub) + 16u * part);
+        if (POL != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int v = 1; v < NV; v++) acc += sum4(f[t][v]);
+    }
+    out[(size_t)r * WAVE + lane] = acc;
+}
+
 // one wavefront per ray, the product's cooperative rounds
 template <int NV>
 __global__ __launch_bounds__(256) void k_ray_coop(int n, int D, const int32_t *__restrict__ offs,
@@ -154,6 +198,12 @@ static int launch(int variant, int n, int D, const int32_t *offs, const int32_t 
             break;
         }
         case 1: hipLaunchKernelGGL(k_ray_lane<NV>, dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
+        case 10: hipLaunchKernelGGL((k_ray_coop_pol<NV, 0>), dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
+        case 11: hipLaunchKernelGGL((k_ray_coop_pol<NV, 1>), dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
+        case 12: hipLaunchKernelGGL((k_ray_coop_pol<NV, 2>), dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
+        case 13: hipLaunchKernelGGL((k_ray_coop_pol<NV, 3>), dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
+        case 14: hipLaunchKernelGGL((k_ray_coop_pol<NV, 4>), dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
+        case 15: hipLaunchKernelGGL((k_ray_coop_pol<NV, 5>), dim3((n + 3) / 4), dim3(256), 0, st, n, D, offs, live, fv, out, chunk); break;
         case 2: TILE(16, 16) break;
         case 3: TILE(8, 16) break;
         case 4: TILE(32, 16) break;

@@ -22,7 +22,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANTS = {0: "ray order, 8 lanes per vector (the product's)", 1: "ray order, lane = plane",
             2: "16x16 tile, bands of 16 planes, 16 waves", 3: "tile, bands of 8, 16 waves",
             4: "tile, bands of 32, 16 waves", 5: "tile, bands of 16, 8 waves",
-            6: "tile, bands of 64, 16 waves (control: ray order inside a synchronised tile)"}
+            6: "tile, bands of 64, 16 waves (control: ray order inside a synchronised tile)",
+            10: "ray order, all 32 loads of a chunk in flight, default cache policy",
+            11: "... nt", 12: "... sc0", 13: "... sc1", 14: "... sc0 sc1", 15: "... sc0 sc1 nt"}
 
 
 def build():
