@@ -31,6 +31,7 @@ accumulator and one all-reduce (RCCL) per BP iteration merges them before the
 prior is added once.
 """
 import ctypes
+import itertools
 import weakref
 
 import numpy as np
@@ -678,7 +679,11 @@ class RayNetForwardPass(ForwardPass):
 
     @staticmethod
     def _new_set(V, HW, cuda):
-        return dict(host=torch.empty((V, HW), dtype=torch.float32, pin_memory=cuda), leases=0)
+        # `live`: one token per array out there.  set.add / set.discard are single operations under
+        # the GIL, so a finaliser running in the middle of a pass (or in another thread) cannot
+        # lose an update the way a counter's read-modify-write could
+        return dict(host=torch.empty((V, HW), dtype=torch.float32, pin_memory=cuda), live=set(),
+                    tokens=itertools.count())
 
     def _take_set(self, plan, V, HW, cuda):
         """-> (key, set, leased): a set of pinned maps this pass may write -- one nobody holds a
@@ -686,7 +691,7 @@ class RayNetForwardPass(ForwardPass):
         if self.options.maps == "lease":
             pool = plan["sets"]
             for i, st in enumerate(pool):
-                if st["leases"] == 0:
+                if not st["live"]:
                     return i, st, True
             if len(pool) < self.MAX_LEASED_SETS:
                 pool.append(self._new_set(V, HW, cuda))
@@ -700,11 +705,10 @@ class RayNetForwardPass(ForwardPass):
         """Image k of the set as an ndarray that owns a lease on the set's memory."""
         row = st["host"][k]
         owner = (ctypes.c_float * row.numel()).from_address(row.data_ptr())
-        st["leases"] += 1
-
-        def release(st=st):         # (keeps the set -- and its pinned tensor -- alive until then)
-            st["leases"] -= 1
-        weakref.finalize(owner, release)
+        token = next(st["tokens"])
+        st["live"].add(token)
+        # (the finaliser's arguments keep the set -- and its pinned tensor -- alive until then)
+        weakref.finalize(owner, lambda st, token: st["live"].discard(token), st, token)
         return np.frombuffer(owner, dtype=np.float32)
 
     def _epilogue_buffers(self, plan, refs, H, W, dev, world, rank, collective):

@@ -473,7 +473,7 @@ def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
         got = np.stack(run(fp, T))          # (np.stack copies; the leases end here)
         assert np.array_equal(got, truth[T])
     pool = fp._plan["sets"]
-    assert len(pool) == 1 and pool[0]["leases"] == 0 and fp._plan["scratch"] is None
+    assert len(pool) == 1 and len(pool[0]["live"]) == 0 and fp._plan["scratch"] is None
     a = run(fp, 3)
     base = pool[0]["host"]
     lo, hi = base.data_ptr(), base.data_ptr() + base.numel() * 4
@@ -481,7 +481,7 @@ def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
     keep = a[2][5:9, 7:11]                  # a slice of one map, kept; the rest dropped
     del a
     gc.collect()
-    assert pool[0]["leases"] == 1
+    assert len(pool[0]["live"]) == 1
     b = run(fp, 1)                          # set 0 is leased: another set
     assert len(pool) == 2 and np.array_equal(np.stack(b), truth[1])
     c = run(fp, 2)                          # `keep` holds set 0, `b` set 1: a third
@@ -489,9 +489,9 @@ def test_maps_of_a_pass_are_never_overwritten_under_a_caller(torch):
     assert np.array_equal(keep, truth[3][2][5:9, 7:11]) and np.array_equal(np.stack(b), truth[1])
     del keep, b, c
     gc.collect()
-    assert [st["leases"] for st in pool] == [0, 0, 0]
+    assert [len(st["live"]) for st in pool] == [0, 0, 0]
     d = run(fp, 3)                          # back on set 0, nothing new
-    assert len(pool) == 3 and pool[0]["leases"] == 5 and np.array_equal(np.stack(d), truth[3])
+    assert len(pool) == 3 and len(pool[0]["live"]) == 5 and np.array_equal(np.stack(d), truth[3])
     # a caller that hoards: beyond MAX_LEASED_SETS sets of pinned memory it gets pageable copies
     hoard = [d] + [run(fp, 1 + i % 3) for i in range(fp.MAX_LEASED_SETS + 1)]
     assert len(pool) == fp.MAX_LEASED_SETS and fp._plan["scratch"] is not None

@@ -188,19 +188,19 @@ def test_leased_maps_return_their_set_when_the_last_view_dies():
     plan = dict(sets=[], scratch=None)
     V, HW = 3, 8
     k0, s0, leased = fp._take_set(plan, V, HW, False)
-    assert (k0, leased) == (0, True) and s0["leases"] == 0
+    assert (k0, leased) == (0, True) and len(s0["live"]) == 0
     s0["host"].copy_(__import__("torch").arange(V * HW, dtype=__import__("torch").float32).view(V, HW))
     a = [fp._lease(s0, k) for k in range(V)]
-    assert s0["leases"] == 3 and a[1][2] == 10.0 and a[1].ctypes.data == s0["host"][1].data_ptr()
+    assert len(s0["live"]) == 3 and a[1][2] == 10.0 and a[1].ctypes.data == s0["host"][1].data_ptr()
     view = a[2].reshape(4, 2).T[1:, 1:]
     del a
     gc.collect()
-    assert s0["leases"] == 1                         # the slice of image 2 is still out there
+    assert len(s0["live"]) == 1                         # the slice of image 2 is still out there
     k1, s1, _ = fp._take_set(plan, V, HW, False)
     assert k1 == 1 and s1 is not s0
     del view
     gc.collect()
-    assert s0["leases"] == 0 and fp._take_set(plan, V, HW, False)[0] == 0
+    assert len(s0["live"]) == 0 and fp._take_set(plan, V, HW, False)[0] == 0
     held = []
     for i in range(fp.MAX_LEASED_SETS + 2):
         k, st, leased = fp._take_set(plan, V, HW, False)
@@ -210,3 +210,32 @@ def test_leased_maps_return_their_set_when_the_last_view_dies():
     assert len(plan["sets"]) == fp.MAX_LEASED_SETS and plan["scratch"] is not None
     fp.options = PathOptions(maps="copy")
     assert fp._take_set(plan, V, HW, False)[0] == -1
+
+
+def test_leases_taken_and_dropped_from_several_threads():
+    """The lease book-keeping is a set of tokens (single add / discard operations), not a counter:
+    eight threads leasing and dropping arrays of one set at once leave it free, and it is never
+    seen free while an array is held."""
+    import gc
+    import threading
+    from raynet_amd.forward_pass import RayNetForwardPass
+    st = RayNetForwardPass._new_set(2, 16, False)
+    keep = RayNetForwardPass._lease(st, 0)             # held throughout: the set is never free
+    seen_free = []
+
+    def worker():
+        for i in range(2000):
+            a = RayNetForwardPass._lease(st, i & 1)
+            if not st["live"]:
+                seen_free.append(i)
+            del a
+    threads = [threading.Thread(target=worker) for _ in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    gc.collect()
+    assert not seen_free and len(st["live"]) == 1
+    del keep
+    gc.collect()
+    assert not st["live"]
