@@ -15,21 +15,15 @@ namespace {
 
 constexpr int BLOCK = 256;               // 4 wavefronts = 4 rays per workgroup
 constexpr int BOX_PROBE_LAUNCHES = 12;   // scatter launches after a reset whose overflow counters are read back
-// threads per workgroup of the wave-per-ray MRF kernels (k_bp, k_depth): A/B knob
-#ifndef RN_RAY_BLOCK
-#define RN_RAY_BLOCK 256
-#endif
+constexpr int RAY_BLOCK = 256;           // threads per workgroup of the wave-per-ray MRF kernels (k_bp, k_depth)
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
-// The plane sweep's own workgroup size (A/B knob, round 5).  The hardware deals consecutive
+// The plane sweep's own workgroup size.  The hardware deals consecutive
 // workgroups to different CUs, so only a workgroup's own rays share a CU's L1, and the kernel runs
 // at the rate its L1s get lines from the L2 -- yet more rays per workgroup do not pay: 384 / 512 /
 // 768 / 1024 threads are 22 / 7 / 13 / 36 % slower than 256 at config 2 and 14 / 2 / 14 / 10 % at
 // config 4 (profiles/r05_exp_sweep_block.txt; a first run that seemed to gain 11 % had silently
 // dropped the folded first BP iteration, whose LDS rows no longer fitted).
-#ifndef RN_SWEEP_BLOCK
-#define RN_SWEEP_BLOCK 256
-#endif
-constexpr int SWEEP_BLOCK = RN_SWEEP_BLOCK;
+constexpr int SWEEP_BLOCK = 256;
 constexpr int SWEEP_WAVES = SWEEP_BLOCK / WAVE;
 constexpr int NXCD = 8;
 
@@ -46,23 +40,10 @@ constexpr int NXCD = 8;
 // became non-temporal; re-measured after that, chunks of 256 - 1024 rays -- one to four 16 x 16
 // pixel tiles -- are 1.5 % faster at config 2 and 6.5 % at config 4, 64 rays are slower, 16384
 // much slower.)
-#ifdef RN_SWEEP_BLOCK
-#define RN_SWEEP_BLOCK_OR_DEFAULT RN_SWEEP_BLOCK
-#else
-#define RN_SWEEP_BLOCK_OR_DEFAULT 256
-#endif
-#ifndef RN_XCD_CHUNK_SWEEP
-#define RN_XCD_CHUNK_SWEEP (2048 * 64 / RN_SWEEP_BLOCK_OR_DEFAULT)      /* workgroups: 2048 rays */
-#endif
-#ifndef RN_XCD_CHUNK_BP
+#define RN_XCD_CHUNK_SWEEP (2048 * 64 / 256)      /* workgroups: 2048 rays */
 #define RN_XCD_CHUNK_BP 256
-#endif
-#ifndef RN_XCD_CHUNK_DEPTH
 #define RN_XCD_CHUNK_DEPTH 0
-#endif
-#ifndef RN_XCD_CHUNK_SCATTER
 #define RN_XCD_CHUNK_SCATTER 8
-#endif
 template <int CHUNK = 0>
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
     if (CHUNK > 0) {
@@ -95,16 +76,11 @@ template <int BS = BLOCK, int CHUNK = 0>
 __device__ __forceinline__ int ray_of_wave(int n, int &lane, int chunk_rt = 0) {
     constexpr int WPB = BS / WAVE;
     lane = threadIdx.x & (WAVE - 1);
-#ifdef RN_HIDDEN_ARG_DIMS
-    const int b = xcd_block<CHUNK>(blockIdx.x, gridDim.x);
-    const int r = uniform(b * (int)(blockDim.x >> 6) + (threadIdx.x >> 6));
-#else
     const int b = chunk_rt > 0 ? xcd_block_rt(blockIdx.x, (n + WPB - 1) / WPB, chunk_rt)
                                : xcd_block<CHUNK>(blockIdx.x, (n + WPB - 1) / WPB);
     // the wave's ray index lives in an SGPR (the compiler cannot see that threadIdx.x >> 6 is
     // wave-uniform): row addresses become scalar base + per-lane 32-bit offset
     const int r = uniform(b * WPB + (int)(threadIdx.x >> 6));
-#endif
     return r < n ? r : -1;
 }
 
@@ -357,7 +333,7 @@ int fail(rn_ctx *ctx, int code, const char *fmt, ...) {
 
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ray_blocks(int n) { return (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; }
-inline int ray_blocks_mrf(int n) { return (n + RN_RAY_BLOCK / WAVE - 1) / (RN_RAY_BLOCK / WAVE); }
+inline int ray_blocks_mrf(int n) { return (n + RAY_BLOCK / WAVE - 1) / (RAY_BLOCK / WAVE); }
 inline int thread_blocks(int n) { return (n + BLOCK - 1) / BLOCK; }
 inline int fill_blocks(int64_t n) {
     int64_t b = (n + BLOCK - 1) / BLOCK;
@@ -429,7 +405,7 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
         switch (p.N) {
 #define RN_CASE(NV_)                                                  \
     case NV_:                                                         \
-        launch_sweep_t<2, NV_, 8 / RN_SWEEP_V4, MAPMODE, PACKED>(ctx, a, st);       \
+        launch_sweep_t<2, NV_, 8 / SWEEP_V4, MAPMODE, PACKED>(ctx, a, st);       \
         return;
             RN_CASE(2) RN_CASE(3) RN_CASE(4) RN_CASE(5) RN_CASE(6) RN_CASE(7) RN_CASE(8) RN_CASE(9)
 #undef RN_CASE
@@ -453,12 +429,8 @@ inline int2 *slab_boxes_for(const rn_ctx *ctx, const int32_t *vox, int64_t n, bo
 // workgroups per box-scatter tile (grid.y): enough of them for ~16 per CU
 inline int box_split(int n, int tile_rays) {
     const int tiles = (n + tile_rays - 1) / tile_rays;
-#ifndef RN_BOX_SPLIT_TARGET
 #define RN_BOX_SPLIT_TARGET 4096
-#endif
-#ifndef RN_BOX_SPLIT_MAX
 #define RN_BOX_SPLIT_MAX 4
-#endif
     // (RAYNET_HIP_BOX_SPLIT="target,max": A/B override, read once)
     static int target = 0, most = 0;
     if (!target) {
@@ -490,15 +462,11 @@ void launch_bp_kernel(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, c
     const int zero4 = zero ? (int)(acc_floats(ctx) / 4) : 0;
 #define RN_BP_(NCH_, STEADY_)                                                                   \
     hipLaunchKernelGGL((k_bp<NCH_, PACKED, CLIP_IN, STEADY_>), dim3(ray_blocks_mrf(n)),             \
-                       dim3(RN_RAY_BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in,         \
+                       dim3(RAY_BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc_in, msgs_in,         \
                        msgs_out, am.uniform ? 1 : 0, am.bias, am.biased ? 1 : 0, zero, zero4)
     // the plan path's iterations after the first: everything the kernel would test per chunk
     // is known here (k_bp's STEADY)
-#ifndef RN_BP_NO_STEADY
     const bool steady = PACKED && !CLIP_IN && msgs_in && !am.uniform && am.biased;
-#else
-    const bool steady = false;
-#endif
 #define RN_BP(NCH_) do { if (steady) RN_BP_(NCH_, true); else RN_BP_(NCH_, false); } while (0)
     if (nch <= 2) RN_BP(2);
     else if (nch <= 4) RN_BP(4);
@@ -525,9 +493,7 @@ void launch_scatter_kernel(rn_ctx *ctx, int n, const float *msgs, const int32_t 
                        dim3(BLOCK), (CAP) * sizeof(double), st, ctx->p, n, msgs, vox, rvc, acc_out, \
                        ctx->box_stats, CAP,                                                       \
                        (const int2 *)(PACKED ? slab_boxes_for(ctx, vox, n, true) : nullptr), items)
-#ifndef RN_BOX0_CAP
 #define RN_BOX0_CAP 4096
-#endif
     if (level == 0) {
         if (fixed) RN_BOX(128, 32, true, RN_BOX0_CAP); else RN_BOX(128, 32, false, RN_BOX0_CAP);
     } else if (level == 1) {
@@ -631,16 +597,12 @@ int launch_depth(rn_ctx *ctx, int n, const float *Sv, const int32_t *vox, const 
     ProfScope prof(ctx, RN_K_DEPTH, n, st);
 #define RN_DE_(NCH_, STEADY_)                                                                   \
     hipLaunchKernelGGL((k_depth<NCH_, PACKED, CLIP_IN, STEADY_>), dim3(ray_blocks_mrf(n)),          \
-                       dim3(RN_RAY_BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, \
+                       dim3(RAY_BLOCK), 0, st, ctx->p, n, Sv, vox, rvc, acc, msgs, ctx->axes, cc, \
                        S_new, depth_map, rays_per_center, am.bias, am.biased ? 1 : 0, cc_stride, dest)
     // (k_depth's STEADY form -- its flags known at compile time, as k_bp's: slower with plain
     // row loads, 0.746 -> 0.772 ms per step, faster with the non-temporal ones, 0.717 -> 0.699;
     // -DRN_DEPTH_NO_STEADY: the generic kernel)
-#ifndef RN_DEPTH_NO_STEADY
     const bool steady = PACKED && !CLIP_IN && msgs && !S_new && depth_map && am.biased;
-#else
-    const bool steady = false;
-#endif
 #define RN_DE(NCH_) do { if (steady) RN_DE_(NCH_, true); else RN_DE_(NCH_, false); } while (0)
     if (nch <= 2) RN_DE(2);
     else if (nch <= 4) RN_DE(4);
@@ -688,57 +650,6 @@ const char *rn_version(void) {
 #endif
 #ifdef RN_EXACT_BP_MATH
         " RN_EXACT_BP_MATH"
-#endif
-#ifdef RN_IEEE_QUOTIENTS
-        " RN_IEEE_QUOTIENTS"
-#endif
-#ifdef RN_MAP_WALK
-        " RN_MAP_WALK"
-#endif
-#ifdef RN_NO_FOLD_FIRST_SWEEP
-        " RN_NO_FOLD_FIRST_SWEEP"
-#endif
-#ifdef RN_OCC_TWO_TERMS
-        " RN_OCC_TWO_TERMS"
-#endif
-#ifdef RN_CLAMP_MINMAX
-        " RN_CLAMP_MINMAX"
-#endif
-#ifdef RN_PROJECTION_FROM_ZERO
-        " RN_PROJECTION_FROM_ZERO"
-#endif
-#ifdef RN_QUOTIENT_HALF_AWAY
-        " RN_QUOTIENT_HALF_AWAY"
-#endif
-#ifdef RN_PHASE_TIMERS
-        " RN_PHASE_TIMERS"
-#endif
-#ifdef RN_SCATTER_STATS
-        " RN_SCATTER_STATS"
-#endif
-#ifdef RN_BP_NO_STEADY
-        " RN_BP_NO_STEADY"
-#endif
-#ifdef RN_DEPTH_NO_STEADY
-        " RN_DEPTH_NO_STEADY"
-#endif
-#ifdef RN_OVERFLOW_BY_RESCAN
-        " RN_OVERFLOW_BY_RESCAN"
-#endif
-#ifdef RN_FIRST_SWEEP_SCAN_PER_CHUNK
-        " RN_FIRST_SWEEP_SCAN_PER_CHUNK"
-#endif
-#ifdef RN_HIDDEN_ARG_DIMS
-        " RN_HIDDEN_ARG_DIMS"
-#endif
-#ifdef RN_CLASS_VIA_BALLOT
-        " RN_CLASS_VIA_BALLOT"
-#endif
-#ifdef RN_DEPTH_RELOAD_VOXEL
-        " RN_DEPTH_RELOAD_VOXEL"
-#endif
-#ifdef RN_TRAV_SCALAR_FLUSH
-        " RN_TRAV_SCALAR_FLUSH"
 #endif
         " | extra:" RN_BUILD_EXTRA;
     return v;
@@ -1489,12 +1400,10 @@ int rn_scene_run(rn_ctx *ctx, const rn_scene_plan *pl, int32_t phases, int32_t i
     bool folded = false;
     if (phases & RN_RUN_PREPARE) {
         if (fixed) RN_HIP(ctx, hipMemsetAsync(pl->acc_fixed, 0, sizeof(int64_t) * G, st));
-#ifndef RN_NO_FOLD_FIRST_SWEEP
         // K1 prefix and BP iteration 0 requested together: the plane sweep writes the first
         // messages itself (one occupancy for every voxel, nothing to gather) while the column
         // is still in LDS; SWEEP(0) below is then the scatter alone
         folded = (phases & RN_RUN_SWEEP) && iteration == 0 && fold_fits(ctx->p);
-#endif
         if (pl->n > 0)
             rc = scene_prepare_all_impl(ctx, pl->n_images, pl->n, pl->rows_per_image, pl->ray_idxs,
                                         pl->features_views, pl->cameras, pl->order, pl->vox,
@@ -1659,32 +1568,6 @@ int rn_prof_offsets(rn_ctx *ctx, float *start_ms_host) {
     return RN_OK;
 }
 
-#ifdef RN_PHASE_TIMERS
-int rn_debug_phase(unsigned long long *out_host, int reset) {
-    if (out_host &&
-        hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess)
-        return RN_ERR_HIP;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return RN_ERR_HIP;
-    }
-    return RN_OK;
-}
-#endif
-#ifdef RN_SCATTER_STATS
-int rn_debug_scatter_stats(unsigned long long *out_host, int reset) {
-    if (out_host &&
-        hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_scatter_stats), sizeof(unsigned long long) * 8) !=
-            hipSuccess)
-        return RN_ERR_HIP;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scatter_stats), z, sizeof(z)) != hipSuccess)
-            return RN_ERR_HIP;
-    }
-    return RN_OK;
-}
-#endif
 
 int rn_timer_start(rn_ctx *ctx, void *stream) {
     if (!ctx) return RN_ERR_INVALID;

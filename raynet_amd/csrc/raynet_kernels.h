@@ -135,14 +135,9 @@ __device__ __forceinline__ void wave_sync() {
 // utils.cu:1-3, min(max(x, a), b) with a < b: the median of the three, one v_med3_f32 -- which for
 // a NaN x returns min3 = a, what fmaxf(NaN, a) passes on (fminf / fmaxf each canonicalise their
 // argument first: three instructions; only a SIGNALLING NaN would differ, and every value the
-// path clamps is the result of an arithmetic instruction, which quiets it).  -DRN_CLAMP_MINMAX:
-// the literal form.
+// path clamps is the result of an arithmetic instruction, which quiets it).
 __device__ __forceinline__ float clampf(float x, float a, float b) {
-#ifndef RN_CLAMP_MINMAX
     return __builtin_amdgcn_fmed3f(x, a, b);
-#else
-    return fminf(fmaxf(x, a), b);
-#endif
 }
 
 // ------------------------------------------------- exact arithmetic shortcuts
@@ -175,11 +170,7 @@ __device__ __forceinline__ bool reciprocal_is_normal(float rcp_n) {
 // three-instruction half-away form; an exact half-way q' has |q' - rndne(q')| = 1/2: not sure.)
 __device__ __forceinline__ float round_quotient_fast(float x, float rcp_n, bool &sure) {
     const float q = x * rcp_n;
-#ifdef RN_QUOTIENT_HALF_AWAY
-    const float r = round_half_away(q);
-#else
     const float r = __builtin_rintf(q);
-#endif
     sure = __builtin_fabsf(q - r) < __builtin_fmaf(__builtin_fabsf(q), -0x1p-21f, 0.5f);
     return r;
 }
@@ -248,7 +239,7 @@ __device__ __forceinline__ int feature_offset(const Params &p, const float *__re
 // decides either way), the clamp as one v_med3_f32 before the conversion (NaN -> 0 like the
 // saturating v_cvt_i32_f32), a 24-bit multiply and a shift instead of two 32-bit multiplies,
 // and the two IEEE divisions only for the wavefronts in which some lane's quotient is too close
-// to a rounding boundary for round_quotient_fast (-DRN_IEEE_QUOTIENTS: always).
+// to a rounding boundary for round_quotient_fast.
 // (in three pieces, so that a wavefront can project into ALL views first and decide once
 // whether any of them needs the IEEE quotients: sweep_coop)
 // 1: the matrix product and the quotients' fast form; `sure`: lanes whose x AND y quotients
@@ -261,18 +252,10 @@ __device__ __forceinline__ void project_fast(const float *__restrict__ Pv, const
     // literal one only in the sign of a zero result.  For the numerators that sign is lost:
     // x = +-0 -> quotient +-0 (or NaN for n = 0 either way) -> rounds to +-0 -> + padding.  The
     // DENOMINATOR keeps the literal form: the sign of n = 0 is the sign of an infinite quotient.
-    // (-DRN_PROJECTION_FROM_ZERO: all three literal.)
-#ifndef RN_PROJECTION_FROM_ZERO
     x = Pv[0] * point[0]; y = Pv[4] * point[0]; n = 0.0f;
     x += Pv[1] * point[1]; x += Pv[2] * point[2]; x += Pv[3] * 1;
     y += Pv[5] * point[1]; y += Pv[6] * point[2]; y += Pv[7] * 1;
     n += Pv[8] * point[0]; n += Pv[9] * point[1]; n += Pv[10] * point[2]; n += Pv[11] * 1;
-#else
-    x = 0.0f; y = 0.0f; n = 0.0f;
-    x += Pv[0] * point[0]; x += Pv[1] * point[1]; x += Pv[2] * point[2]; x += Pv[3] * 1;
-    y += Pv[4] * point[0]; y += Pv[5] * point[1]; y += Pv[6] * point[2]; y += Pv[7] * 1;
-    n += Pv[8] * point[0]; n += Pv[9] * point[1]; n += Pv[10] * point[2]; n += Pv[11] * 1;
-#endif
     const float rn = __builtin_amdgcn_rcpf(n);
     bool sure_x, sure_y;
     rx = round_quotient_fast(x, rn, sure_x);
@@ -280,11 +263,7 @@ __device__ __forceinline__ void project_fast(const float *__restrict__ Pv, const
     // (the class test straight into a lane mask: through ballot(bool) the compiler turns the
     // v_cmp_class result into 0 / 1 and compares that again, two instructions per view)
     unsigned long long normal_rcp;
-#ifndef RN_CLASS_VIA_BALLOT
     asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(normal_rcp) : "v"(rn), "v"(0x108));
-#else
-    normal_rcp = __builtin_amdgcn_ballot_w64(reciprocal_is_normal(rn));
-#endif
     sure = __builtin_amdgcn_ballot_w64(sure_x) & __builtin_amdgcn_ballot_w64(sure_y) & normal_rcp;
 }
 // 2: the reference's own quotients (feature_similarities.cu:31-36)
@@ -307,18 +286,10 @@ __device__ __forceinline__ int feature_offset_bytes(const Params &p,
                                                     const float *__restrict__ Pv,
                                                     const float point[3], float pad_shift) {
     float x, y, n, rx, ry;
-#ifndef RN_IEEE_QUOTIENTS
     unsigned long long sure;
     project_fast(Pv, point, x, y, n, rx, ry, sure);
     if (sure != __builtin_amdgcn_read_exec())         // ~4 % of the wavefronts per view at config 2
         project_ieee(x, y, n, rx, ry);
-#else
-    x = 0.0f; y = 0.0f; n = 0.0f;
-    x += Pv[0] * point[0]; x += Pv[1] * point[1]; x += Pv[2] * point[2]; x += Pv[3] * 1;
-    y += Pv[4] * point[0]; y += Pv[5] * point[1]; y += Pv[6] * point[2]; y += Pv[7] * 1;
-    n += Pv[8] * point[0]; n += Pv[9] * point[1]; n += Pv[10] * point[2]; n += Pv[11] * 1;
-    project_ieee(x, y, n, rx, ry);
-#endif
     return project_offset<LOG2_VEC_BYTES>(p, rx, ry, pad_shift);
 }
 
@@ -361,24 +332,8 @@ __device__ __forceinline__ void sweep_generic(const Params &p, const FeatureView
 // contiguous segment (a whole 128-B line for F=32), 16*V4 bytes per lane, 64/LPS planes per
 // load round.  Each lane multiplies its 4*V4 channels for all view pairs, the LPS partial
 // sums are folded with an xor butterfly.
-#ifndef RN_SWEEP_V4
-#define RN_SWEEP_V4 1
-#endif
-// -DRN_SWEEP_STOP=n: k_sweep_map's wavefronts end after phase n -- 1 loads of segment / count / voxel
-// row, 12 projection, 2 gathers + pair sums, 3 softmax, 4 planes -> voxels, 45 clip + renormalise
-// (5: everything, the first BP iteration's messages included) -- so that SQ_INSTS_VALU of two
-// builds differs by one phase's EXECUTED instructions (tools/sweep_phase_budget.py).  Never set
-// in the shipped library (rn_version() names every -D of a variant build).
-#ifndef RN_SWEEP_STOP
-#define RN_SWEEP_STOP 0
-#endif
-#ifndef RN_SWEEP_UNROLL2_MAX_VIEWS
-#define RN_SWEEP_UNROLL2_MAX_VIEWS 6
-#endif
-// views whose projection matrices may stay in SGPRs across the chunk loop (see sweep_coop)
-#ifndef RN_SWEEP_SGPR_VIEWS
-#define RN_SWEEP_SGPR_VIEWS 16
-#endif
+constexpr int SWEEP_V4 = 1;                 // float4s per lane and view
+constexpr int SWEEP_UNROLL2_MAX_VIEWS = 6;  // two load rounds in flight up to this many views
 // x + (x of the lane the DPP control names), one VALU instruction, no LDS round trip.
 // quad_perm:[1,0,3,2] / [2,3,0,1] = xor 1 / xor 2; row_half_mirror pairs lane i with 7-i of
 // its group of 8, which sums the two quads once they are quad-uniform.
@@ -449,17 +404,26 @@ __device__ __forceinline__ float sweep_round(const float *const (&vbase)[NV], co
     return acc;
 }
 
-// the LPS load rounds of one 64-plane chunk; returns the pair sum of the plane this lane ends
-// up holding, `mine_round` says which (plane = mine_round * SPL + sub)
-template <int NV, int LPS, int V4, bool REF_HELD>
+// the LPS load rounds of one 64-sample chunk; returns the pair sum of the sample this lane ends up
+// holding, `mine_round` says which (sample = mine_round * SPL + sub).
+// RPW rays share the wavefront (sweep_coop): sample j is plane j % DPAD of ray j / DPAD, DPAD =
+// 64 / RPW; a load round's 64 / LPS samples never straddle two rays (DPAD >= 16), so the held
+// vector of view 0 is ref[ray of the round].  `live` = planes of a ray that exist (D, or what is
+// left of D in this chunk when RPW = 1), `nrays` = rays of this wavefront that exist: rounds whose
+// samples are all beyond either are skipped (wave-uniform) -- the cost of a sweep is proportional
+// to D as the reference's loop is (feature_similarities.cu:84), not to 64.
+template <int NV, int LPS, int V4, bool REF_HELD, int RPW>
 __device__ __forceinline__ float sweep_rounds(const float *const (&vbase)[NV], const int (&offb)[NV],
                                               int sub, int part, unsigned part_bytes,
-                                              const float2v (&ref)[2 * V4], int &mine_round) {
+                                              const float2v (&ref)[RPW][2 * V4], int live, int nrays,
+                                              int &mine_round) {
     constexpr int SPL = WAVE / LPS;
+    constexpr int DPAD = WAVE / RPW;
+    static_assert(DPAD % (2 * SPL) == 0 || LPS != 8, "a pair of load rounds stays within one ray");
     float mine = 0.0f;
     // The LPS partial sums of a plane are folded across its lanes with DPP adds (no LDS
     // permutes).
-    if (LPS == 8 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS) {
+    if (LPS == 8 && NV <= SWEEP_UNROLL2_MAX_VIEWS) {
         // two rounds of loads in flight while the view count leaves registers for it, and
         // their two reductions transposed: "odd" lanes fold round 2t+1, the others round
         // 2t, so the xor-1 step serves both rounds at once.  The last step, lane i with
@@ -467,9 +431,13 @@ __device__ __forceinline__ float sweep_rounds(const float *const (&vbase)[NV], c
         // "odd" is flipped in the upper quad to meet it.
         const bool odd = (part ^ (part >> 2)) & 1;
         mine_round = (part & ~1) | (int)odd;
+#pragma unroll
         for (int t = 0; t < LPS / 2; t++) {
-            const float a0 = sweep_round<NV, V4, REF_HELD>(vbase, offb, (2 * t) * SPL + sub, part_bytes, ref);
-            const float a1 = sweep_round<NV, V4, REF_HELD>(vbase, offb, (2 * t + 1) * SPL + sub, part_bytes, ref);
+            const int first = (2 * t) * SPL;             // first sample of the pair of rounds
+            if (first % DPAD >= live || first / DPAD >= nrays) continue;
+            const float2v(&rf)[2 * V4] = ref[RPW == 1 ? 0 : first / DPAD];
+            const float a0 = sweep_round<NV, V4, REF_HELD>(vbase, offb, first + sub, part_bytes, rf);
+            const float a1 = sweep_round<NV, V4, REF_HELD>(vbase, offb, first + SPL + sub, part_bytes, rf);
             const float stay = odd ? a1 : a0, moved = odd ? a0 : a1;
             float r;
             RN_ADD_DPP(r, moved, stay, RN_DPP_XOR1);
@@ -480,8 +448,12 @@ __device__ __forceinline__ float sweep_rounds(const float *const (&vbase)[NV], c
     } else {
         static_assert(LPS <= 8, "sweep_coop folds at most 8 lanes per plane");
         mine_round = part;
+#pragma unroll
         for (int it = 0; it < LPS; it++) {
-            float acc = sweep_round<NV, V4, REF_HELD>(vbase, offb, it * SPL + sub, part_bytes, ref);
+            const int first = it * SPL;
+            if (first % DPAD >= live || first / DPAD >= nrays) continue;
+            float acc = sweep_round<NV, V4, REF_HELD>(vbase, offb, first + sub, part_bytes,
+                                                      ref[RPW == 1 ? 0 : first / DPAD]);
             if (LPS >= 2) RN_ADD_DPP(acc, acc, acc, RN_DPP_XOR1);
             if (LPS >= 4) RN_ADD_DPP(acc, acc, acc, RN_DPP_XOR2);
             if (LPS >= 8) RN_ADD_DPP(acc, acc, acc, RN_DPP_MIRROR8);
@@ -491,17 +463,24 @@ __device__ __forceinline__ float sweep_rounds(const float *const (&vbase)[NV], c
     return mine;
 }
 
-template <int NV, int LPS, bool FAST = false>
+// RPW = 1: the wavefront's ray has the segment s -> e (wave-uniform), lane k projects plane
+// base + k, Sl[D] receives the column.  RPW = 2 / 4 (D <= 32 / 16, k_sweep_map_packed): the
+// wavefront takes RPW rays at once, lane l = plane l % DPAD of ray l / DPAD with that ray's
+// segment in ITS s / e; ray q's column goes to Sl[q * D ...]; `nrays` of them exist (the lanes of
+// a missing ray shadow the last one).  The arithmetic per (ray, plane) sample is the same
+// instruction sequence either way: the columns are the same bits.
+template <int NV, int LPS, bool FAST = false, int RPW = 1>
 __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &fv,
                                            const float *const *__restrict__ tbl,
                                            const float *__restrict__ P, const float s[3],
-                                           const float e[3], int lane, float *Sl) {
+                                           const float e[3], int lane, float *Sl, int nrays = 1) {
     constexpr int SPL = WAVE / LPS;       // planes per load round
-    constexpr int V4 = RN_SWEEP_V4;       // float4s per lane and view
+    constexpr int V4 = SWEEP_V4;          // float4s per lane and view
+    constexpr int DPAD = WAVE / RPW;      // lanes (= plane slots) per ray
     const float *vbase[NV];               // uniform per-view bases (kernel argument or table)
 #pragma unroll
     for (int v = 0; v < NV; v++) vbase[v] = tbl ? tbl[v] : fv.v[v];
-    const int sub = lane / LPS;           // which plane of the group
+    const int sub = lane / LPS;           // which sample of the load round
     const int part = lane % LPS;          // which float4 of the vector
     const unsigned part_bytes = (16u * V4) * (unsigned)part;
     const int pairs = (NV * (NV - 1)) / 2;
@@ -509,11 +488,12 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
     constexpr int LOG2_VEC_BYTES = LPS * V4 == 8 ? 7 : LPS * V4 == 4 ? 6 : LPS * V4 == 2 ? 5 : 4;
     static_assert((16 * V4 * LPS) == (1 << LOG2_VEC_BYTES), "vector bytes must be a power of two");
     const float pad_shift = (float)(p.padding - (p.padding - 1) / 2);
-    for (int base = 0; base < p.D; base += WAVE) {
+    const int q_lane = RPW == 1 ? 0 : lane / DPAD;
+    for (int base = 0; base < (RPW == 1 ? p.D : 1); base += WAVE) {
         // lane k projects plane base+k into every view
         int offb[NV];           // BYTE offset of the plane's feature vector in every view
         {
-            const int k = min(base + lane, p.D - 1);
+            const int k = min(RPW == 1 ? base + lane : lane % DPAD, p.D - 1);
             float point[3];
             plane_point(s, e, k, p.D, point);
             // The 12 entries of a view's matrix are wave-uniform: scalar loads into SGPRs.  (While
@@ -524,55 +504,87 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
             // at config 4.  What was tried against the spills before that:)
             // Every way of not spilling them was measured SLOWER at config 4 (17.0 -> 18.5 - 20.5
             // ms, with 11 % fewer VALU instructions): reloading a view's matrix where it is used
-            // (the pointer made opaque by an empty asm; -DRN_SWEEP_SGPR_VIEWS=n: from view n on),
+            // (the pointer made opaque by an empty asm),
             // requesting it one view ahead, staging the matrices in LDS -- the reloads' latency,
             // or the asm barriers between the views' projections, cost more than the spill code
             // (profiles/r03_exp_view_matrix_sgprs.txt).
 #pragma unroll
-            for (int v = 0; v < NV; v++) {
-                const float *Pv = P + 12 * v;
-                if (v >= RN_SWEEP_SGPR_VIEWS) asm volatile("" : "+s"(Pv));
-                offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, Pv, point, pad_shift);
-            }
+            for (int v = 0; v < NV; v++)
+                offb[v] = feature_offset_bytes<LOG2_VEC_BYTES>(p, P + 12 * v, point, pad_shift);
         }
-#if RN_SWEEP_STOP == 12      // (instruction budget: the projection alone, its offsets kept alive in LDS)
-        {
-            int keep = 0;
-#pragma unroll
-            for (int v = 0; v < NV; v++) keep ^= offb[v];
-            Sl[lane] = __builtin_bit_cast(float, keep);
-            continue;
-        }
-#endif
-        // View 0 is the reference image itself: every plane of the ray projects onto the
+        // View 0 is the reference image itself: every plane of a ray projects onto the
         // ray's own pixel there (up to the rounding of the projection, which is checked, not
-        // assumed), so its feature vector is fetched once per chunk instead of once per load
-        // round -- a fifth of the sweep's gathers at 5 views.
-        const int off0 = __builtin_amdgcn_readfirstlane(offb[0]);
-        const bool ref_held = __all(offb[0] == off0);
-        float2v ref[2 * V4];
+        // assumed), so its feature vector is fetched once per ray and chunk instead of once per
+        // load round -- a fifth of the sweep's gathers at 5 views.
+        int off0[RPW];
 #pragma unroll
-        for (int c = 0; c < 2 * V4; c++) ref[c] = float2v{0.f, 0.f};
+        for (int q = 0; q < RPW; q++) off0[q] = __builtin_amdgcn_readlane(offb[0], q * DPAD);
+        int off0_mine = off0[0];
+#pragma unroll
+        for (int q = 1; q < RPW; q++) off0_mine = q_lane == q ? off0[q] : off0_mine;
+        const bool ref_held = __all(offb[0] == off0_mine);
+        float2v ref[RPW][2 * V4];
+#pragma unroll
+        for (int q = 0; q < RPW; q++)
+#pragma unroll
+            for (int c = 0; c < 2 * V4; c++) ref[q][c] = float2v{0.f, 0.f};
         if (ref_held) {
             typedef const __attribute__((address_space(1))) char *gptr;
             typedef const __attribute__((address_space(1))) float4v *gptr4;
 #pragma unroll
-            for (int q = 0; q < V4; q++) {
-                const float4v f = *(gptr4)((gptr)vbase[0] + (unsigned)off0 + part_bytes + 16u * q);
-                ref[2 * q] = float2v{f.x, f.y};
-                ref[2 * q + 1] = float2v{f.z, f.w};
-            }
+            for (int q = 0; q < RPW; q++)
+#pragma unroll
+                for (int c = 0; c < V4; c++) {
+                    const float4v f = *(gptr4)((gptr)vbase[0] + (unsigned)off0[q] + part_bytes + 16u * c);
+                    ref[q][2 * c] = float2v{f.x, f.y};
+                    ref[q][2 * c + 1] = float2v{f.z, f.w};
+                }
         }
         float mine = 0.0f;
-        int mine_round;         // which load round's plane this lane ends up holding
+        int mine_round;         // which load round's sample this lane ends up holding
+        const int live = RPW == 1 ? p.D - base : p.D;
         if (ref_held)
-            mine = sweep_rounds<NV, LPS, V4, true>(vbase, offb, sub, part, part_bytes, ref, mine_round);
+            mine = sweep_rounds<NV, LPS, V4, true, RPW>(vbase, offb, sub, part, part_bytes, ref, live, nrays, mine_round);
         else
-            mine = sweep_rounds<NV, LPS, V4, false>(vbase, offb, sub, part, part_bytes, ref, mine_round);
-        const int k = base + mine_round * SPL + sub;
+            mine = sweep_rounds<NV, LPS, V4, false, RPW>(vbase, offb, sub, part, part_bytes, ref, live, nrays, mine_round);
+        const int j = mine_round * SPL + sub;           // the sample this lane holds
+        const int k = RPW == 1 ? base + j : j % DPAD;
+        const int q = RPW == 1 ? 0 : j / DPAD;
         // FAST (resident path): a constant factor of the softmax's input, value-only
-        if (k < p.D) Sl[k] = FAST ? mine * (1.0f / pairs) : mine / pairs;
+        if (k < p.D && q < nrays) Sl[q * p.D + k] = FAST ? mine * (1.0f / pairs) : mine / pairs;
     }
+}
+
+// every lane receives the maximum / the sum over its group of G = 16, 32 or 64 lanes (G = 64:
+// wave_max / wave_sum).  The butterfly is the one RN_WAVE_REDUCE runs, cut off after the rows for
+// G = 16 and after the first row broadcast for G = 32 -- a column of D <= G values padded with the
+// operator's identity gets the very bits the 64-lane reduction gives it.
+#define RN_GROUP_REDUCE16(OP, X)                                                 \
+    RN_SCAN_STEP(OP, X, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");       \
+    RN_SCAN_STEP(OP, X, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");       \
+    RN_SCAN_STEP(OP, X, "row_half_mirror row_mask:0xf bank_mask:0xf");           \
+    RN_SCAN_STEP(OP, X, "row_mirror row_mask:0xf bank_mask:0xf")
+template <int G>
+__device__ __forceinline__ float group_pick(float x, int lane) {
+    if (G == 16) return x;            // every lane of a row holds the row's result
+    // G = 32: after row_bcast:15 the rows 1 and 3 hold the results of lanes 0-31 / 32-63
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 31));
+    const float hi = lane63(x);
+    return lane < 32 ? lo : hi;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float x, int lane) {
+    static_assert(G == 16 || G == 32, "groups of 16 or 32 lanes");
+    RN_GROUP_REDUCE16("v_max_f32_dpp", x);
+    if (G == 32) RN_SCAN_STEP("v_max_f32_dpp", x, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    return group_pick<G>(x, lane);
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float x, int lane) {
+    static_assert(G == 16 || G == 32, "groups of 16 or 32 lanes");
+    RN_GROUP_REDUCE16("v_add_f32_dpp", x);
+    if (G == 32) RN_SCAN_STEP("v_add_f32_dpp", x, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    return group_pick<G>(x, lane);
 }
 
 // a / b for VALUE arithmetic only (never feeds an index): hardware reciprocal when FAST
@@ -616,6 +628,28 @@ __device__ __forceinline__ void softmax_column(int D, int lane, float *Sl) {
     }
     sum = wave_sum(sum);
     for (int k = lane; k < D; k += WAVE) Sl[k] = vdiv<FAST>(Sl[k], sum);
+}
+
+// ... and on the RPW columns of a wavefront that sweeps RPW rays at once (sweep_coop): lane l owns
+// plane l % DPAD of ray l / DPAD; same expressions per element, the reductions per group of lanes
+template <bool FAST, int RPW>
+__device__ __forceinline__ void softmax_columns(int D, int lane, float *Sl) {
+    constexpr int DPAD = WAVE / RPW;
+    const int k = lane % DPAD;
+    float *x = Sl + (lane / DPAD) * D + k;
+    const bool mine = k < D;
+    const float mx = group_max<DPAD>(mine ? *x : -INFINITY, lane);
+    float v = 0.0f;
+    if (mine) {
+        const float d = *x - mx;
+#if !defined(RN_EXACT_OCC_EXP) && !defined(RN_EXACT_SOFTMAX_EXP)
+        v = FAST ? __builtin_amdgcn_exp2f(d * 0x1.715476p+0f) : (d <= 0.0f ? exp_nonpos(d) : expf(d));
+#else
+        v = d <= 0.0f ? exp_nonpos(d) : expf(d);
+#endif
+    }
+    const float sum = group_sum<DPAD>(v, lane);
+    if (mine) *x = vdiv<FAST>(v, sum);
 }
 
 // ------------------------------------------------------------------- a3
@@ -800,28 +834,24 @@ __device__ __forceinline__ float occupancy_to_ray(float acc, float msg) {
     // t1 = exp(0 - max(0,mu)), t2 = exp(mu - max(0,mu)): one of the two is exp(0) = 1
     // exactly, the other exp(-|mu|) -- one exponential gives both, bit for bit
     const float mu = acc - msg;
-#if !defined(RN_EXACT_OCC_EXP) && !defined(RN_OCC_TWO_TERMS)
+#ifndef RN_EXACT_OCC_EXP
     // t2 / (t1 + t2) is 1 / (1 + exp(-mu)) on either side of 0; the reference forms it from
     // exp(-|mu|) so that nothing overflows -- v_exp_f32 and v_rcp_f32 saturate instead (exp(-mu)
-    // = inf -> 0 -> the clamp's 1e-4, as the two-term form gives), NaN stays NaN.  Same error
-    // bound as below (the exponential's), three instructions fewer per voxel.
+    // = inf -> 0 -> the clamp's 1e-4, as the two-term form gives), NaN stays NaN.  v_exp_f32 on
+    // the rounded product mu * log2(e) makes the exponential wrong by <= |mu| * 1.44 * 2^-24
+    // relative: 8e-7 where the occupancy is not clamped anyway (|mu| <= 9.21; CUDA's own expf,
+    // what the reference runs, is specified to 2 ulp = 2.4e-7), an order of magnitude below what
+    // the fp32 subtraction 1 - o already costs the transmittance next to the clamp (6e-8 / 1e-4).
+    // Full-size parity with the C oracle is unchanged by it.
     return clampf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mu * -0x1.715476p+0f)), 1e-4f,
                   (float)(1 - 1e-4));
-#endif
-#ifndef RN_EXACT_OCC_EXP
-    // v_exp_f32 on -|mu| * log2(e): 2 instructions for the library's 11.  The product's
-    // rounding makes exp(-|mu|) wrong by <= |mu| * 1.44 * 2^-24 relative: 8e-7 where the
-    // occupancy is not clamped anyway (|mu| <= 9.21; CUDA's own expf, what the reference runs,
-    // is specified to 2 ulp = 2.4e-7), an order of magnitude below what the fp32 subtraction
-    // 1 - o already costs the transmittance next to the clamp (6e-8 / 1e-4).  Full-size parity
-    // with the C oracle is unchanged by it; NaN and +-inf behave as expf.
-    const float e = __builtin_amdgcn_exp2f(fabsf(mu) * -0x1.715476p+0f);
 #else
+    // the exact-arithmetic build (tests/test_exact_build_gpu.py): the library's own exponential
     const float e = exp_nonpos(0 - fabsf(mu));
-#endif
     const float t1 = mu > 0.0f ? e : 1.0f;
     const float t2 = mu > 0.0f ? 1.0f : e;
     return clampf(bp_div(t2, t1 + t2), 1e-4f, (float)(1 - 1e-4));
+#endif
 }
 
 }  // namespace rn

@@ -68,16 +68,10 @@ __device__ __forceinline__ float gather_acc(const float *__restrict__ acc, int l
 // kernel arguments in one scalar fetch up front -- no gain, the limit was never the dependent
 // round trips (profiles/r02_exp_wave_startup.txt).  What did help is not reading gridDim /
 // blockDim at all: ray_of_wave.)
-#ifndef RN_BP_NT
 #define RN_BP_NT true
-#endif
-#ifndef RN_DEPTH_NT
 #define RN_DEPTH_NT true
-#endif
 // bodies of up to this many chunks issue all their accumulator gathers back to back (bp_ray)
-#ifndef RN_GATHER_BATCH_MAX
 #define RN_GATHER_BATCH_MAX 6
-#endif
 template <int NCH>
 struct RayRows {
     float sv[NCH], mv[NCH];
@@ -300,7 +294,7 @@ __device__ __forceinline__ void bp_ray(const Params &p, int r, int count, int la
 }
 
 template <int NCH, bool PACKED, bool CLIP_IN, bool STEADY = false>
-__global__ __launch_bounds__(RN_RAY_BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
+__global__ __launch_bounds__(RAY_BLOCK) void k_bp(Params p, int n, const float *__restrict__ S,
                                               const int32_t *__restrict__ vox,
                                               const int32_t *__restrict__ rvc,
                                               const float *__restrict__ acc_in,
@@ -312,13 +306,13 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_bp(Params p, int n, const floa
     // launch) is cleared here, a float4 per lane of the first wavefronts, instead of by a
     // kernel of its own between the sweeps
     if (zero_buf) {
-        constexpr int WPB = RN_RAY_BLOCK / WAVE;
+        constexpr int WPB = RAY_BLOCK / WAVE;
         const int nw = (n + WPB - 1) / WPB * WPB;
         const int w = blockIdx.x * WPB + (int)(threadIdx.x >> 6);
         for (int i = w * WAVE + (int)(threadIdx.x & (WAVE - 1)); i < zero_count4; i += nw * WAVE)
             zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int r = ray_of_wave<RN_RAY_BLOCK, RN_XCD_CHUNK_BP>(n, lane);
+    const int r = ray_of_wave<RAY_BLOCK, RN_XCD_CHUNK_BP>(n, lane);
     if (r < 0) return;
     const int count = min(uniform(rvc[r]), p.M);
     if (count <= 1) return;   // mrf_np.py:300: such rays send nothing
@@ -341,12 +335,7 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_bp(Params p, int n, const floa
 // costs one request per line: 21 G/s scattered vs 324 G/s coalesced, tools/atomic_bench.hip).
 // Any ray order is CORRECT (every element is emitted exactly once; the flush loop takes
 // what an unexpected ordering left behind); coherence only buys speed.
-#ifdef RN_SCATTER_STATS
-__device__ unsigned long long g_scatter_stats[8];   // rounds, emitting lanes, tails, 64B segments, chunks
-#endif
-#ifndef RN_SLAB_STEPS
 #define RN_SLAB_STEPS 32
-#endif
 constexpr int SLAB_STEPS = RN_SLAB_STEPS;     // steps of a tile: 16, 32 or 64
 constexpr int SLAB_PAD = SLAB_STEPS + 1;
 template <bool PACKED>
@@ -429,9 +418,6 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
             }
         }
         wave_sync();
-#ifdef RN_SCATTER_STATS
-        if (lane == 0) atomicAdd(&g_scatter_stats[4], 1ull);
-#endif
 
         const int nvalid = min(max(cnt - base, 0), SLAB_STEPS);
         int cursor = 0;
@@ -501,29 +487,6 @@ __global__ __launch_bounds__(WAVE) void k_scatter_slab(Params p, int n,
                 RN_SEG_STEP(0x111) RN_SEG_STEP(0x112) RN_SEG_STEP(0x114) RN_SEG_STEP(0x118)
 #undef RN_SEG_STEP
                 const bool tail = dpp_i<0x101, 0xf>(0x7ffffffe, lin) != lin;   // row_shl:1
-#ifdef RN_SCATTER_STATS
-                {
-                    const bool t = emit && tail;
-                    const unsigned long long bt = __ballot(t);
-                    // distinct 64-byte segments among the issuing lanes (exact count)
-                    int seg = t ? (lin >> 4) : -1;
-                    int distinct = 0;
-                    unsigned long long left = bt;
-                    while (left) {
-                        const int l = __builtin_ctzll(left);
-                        const int sv = __shfl(seg, l);
-                        const unsigned long long same = __ballot(t && seg == sv);
-                        left &= ~same;
-                        distinct++;
-                    }
-                    if (lane == 0) {
-                        atomicAdd(&g_scatter_stats[0], 1ull);
-                        atomicAdd(&g_scatter_stats[1], (unsigned long long)__builtin_popcountll(__ballot(emit)));
-                        atomicAdd(&g_scatter_stats[2], (unsigned long long)__builtin_popcountll(bt));
-                        atomicAdd(&g_scatter_stats[3], (unsigned long long)distinct);
-                    }
-                }
-#endif
                 if (emit) {
                     if (tail)
                         __hip_atomic_fetch_add(acc_out + lin, val, __ATOMIC_RELAXED,
@@ -754,13 +717,6 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
         if (hi0 < 0) return;          // (cannot happen below maxc; uniform anyway)
         const int d0 = hi0 - lo0 + 1, d1 = hi1 - lo1 + 1, d2 = hi2 - lo2 + 1;
         const int V = d0 * d1 * d2;
-#ifdef RN_SCATTER_STATS
-        if (tid == 0) {
-            atomicAdd(&g_scatter_stats[0], 1ull);
-            atomicAdd(&g_scatter_stats[1], V <= BOX_CAP ? 1ull : 0ull);
-            atomicAdd(&g_scatter_stats[2], (unsigned long long)V);
-        }
-#endif
         if (V <= BOX_CAP) {
 #pragma unroll
             for (int k = 0; k < BOX_NB; k++)
@@ -775,7 +731,6 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             return;
         }
         if (tid == 0 && overflow_stats) atomicAdd(overflow_stats + 1, 1u);
-#ifndef RN_OVERFLOW_BY_RESCAN
         // ---- too big for LDS.  With the traversal's slab boxes at hand the chunk is done again
         // slab by slab (64 rows x 16 steps each): every piece's box is already known -- no scan,
         // no workgroup reduction -- and the pairs are still in registers.  (Measured on the
@@ -821,7 +776,6 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_box(Params p, int n,
             }
             return;
         }
-#endif
         // ---- without slab boxes (rows that are not patch-ordered, lists from elsewhere): the
         // chunk again in quarters, pairs re-read (L2-hot); a quarter that still does not fit
         // takes the direct atomics
@@ -995,7 +949,7 @@ struct DepthDest {
     int64_t image_stride = 0;
 };
 template <int NCH, bool PACKED, bool CLIP_IN, bool STEADY = false>
-__global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const float *S,
+__global__ __launch_bounds__(RAY_BLOCK) void k_depth(Params p, int n, const float *S,
                                                  const int32_t *__restrict__ vox,
                                                  const int32_t *__restrict__ rvc,
                                                  const float *__restrict__ acc,
@@ -1006,7 +960,7 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const f
                                                  float acc_bias, int biased, int cc_stride,
                                                  DepthDest dest) {
     int lane;
-    const int r = ray_of_wave<RN_RAY_BLOCK, RN_XCD_CHUNK_DEPTH>(n, lane);
+    const int r = ray_of_wave<RAY_BLOCK, RN_XCD_CHUNK_DEPTH>(n, lane);
     if (r < 0) return;
     const int group = rays_per_center > 0 ? r / rays_per_center : 0;
     if (rays_per_center > 0 && cc) cc += (size_t)cc_stride * group;
@@ -1047,9 +1001,7 @@ __global__ __launch_bounds__(RN_RAY_BLOCK) void k_depth(Params p, int n, const f
         const int mine = best_i;
         best_i = wave_min_i(best == top ? best_i : 0x7fffffff);
         const unsigned long long who = __ballot(best == top && mine == best_i);
-#ifndef RN_DEPTH_RELOAD_VOXEL
         if (who) won_pk = __builtin_amdgcn_readlane(best_pk, (int)__builtin_ctzll(who));
-#endif
         if (best_i == 0x7fffffff) best_i = 0;       // (a NaN column: nobody equals the maximum)
     }
     if (lane == 0) {

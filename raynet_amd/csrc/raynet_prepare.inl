@@ -44,9 +44,7 @@ __global__ void k_first_occupancy(float prior, float *out) { out[0] = occupancy_
 // [64 rays][TRAV_TILE steps] in LDS and writes finished tiles as coalesced row segments
 // (16 steps: 0.42 ms per scene against 0.46 at 32 and 0.70 at 64 -- the tile's LDS decides how
 // many of these serial, latency-bound threads a CU holds).
-#ifndef RN_TRAV_TILE
 #define RN_TRAV_TILE 16
-#endif
 constexpr int TRAV_TILE = RN_TRAV_TILE;     // steps collected per flush (the packed list's slab boxes are per 16-step tile: k_traverse<true> needs 16; 32 / 64 compile for the reference layout only)
 template <bool PACKED>
 __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
@@ -204,7 +202,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
                                                          hi0 < 0 ? -1 : pack_voxel(hi0, hi1, hi2));
         }
         // flush: TRAV_TILE consecutive steps of one ray are one contiguous segment
-#ifndef RN_TRAV_SCALAR_FLUSH
         if (PACKED && TRAV_TILE == 16 && (p.M & 3) == 0) {
             // four steps per lane and store (16-byte aligned: M and the tile base are multiples
             // of 4): 4 store rounds per tile instead of 16; a row's last, partial group of four
@@ -228,7 +225,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
             wave_sync();
             continue;
         }
-#endif
         constexpr int RPI = WAVE / TRAV_TILE;      // rows per instruction
 #pragma unroll 4
         for (int j = 0; j < WAVE; j += RPI) {
@@ -260,21 +256,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(Params p, int n,
 //          2: as 1, then clip_and_renorm (mrf_bp.cu:103-111) -> Sr  (resident-scene path)
 //          3: as 2, then BP iteration 0 of the ray (first_sweep_messages) -> msgs_out
 // Dynamic LDS: [axes gx+gy+gz][plane positions][per wave: D plane column, M values (3 M for 3)]
-// -DRN_PHASE_TIMERS: where a k_sweep_map wavefront's cycles go (tools/phase_timers.py);
-// every 16th ray adds the s_memtime deltas between the marks to g_phase[]
-#ifdef RN_PHASE_TIMERS
-__device__ unsigned long long g_phase[16];
-#define RN_PHASE_DECL unsigned long long ph_t = clock64(); const bool ph_on = (r & 15) == 0
-#define RN_PHASE_MARK(K)                                                          \
-    do {                                                                          \
-        const unsigned long long ph_n = clock64();                                \
-        if (ph_on && lane == 0) atomicAdd(&g_phase[K], ph_n - ph_t);              \
-        ph_t = ph_n;                                                              \
-    } while (0)
-#else
-#define RN_PHASE_DECL
-#define RN_PHASE_MARK(K)
-#endif
 // waves per SIMD the register allocation has to leave room for.  Round 1: 7 (<= 72 VGPRs; the
 // kernel needs 74 unconstrained) -1.8 % on the 5-view sweep, 8 (64 VGPRs) -0.5 %.  Round 2
 // (profiles/r02_exp_knobs.txt, after the ray index moved to an SGPR and rays without voxels
@@ -283,12 +264,8 @@ __device__ unsigned long long g_phase[16];
 // and the 4-view sweep (which would spill) are left alone
 // cache policy of the list's LDS-DMA loads: 2 = non-temporal (read once here; k_sweep_map 2.957 -> 2.904 ms
 // with it: the feature gathers keep the L2), 0 = default
-#ifndef RN_SWEEP_LIST_CPOL
 #define RN_SWEEP_LIST_CPOL 2
-#endif
-#ifndef RN_SWEEP_MIN_WAVES
 #define RN_SWEEP_MIN_WAVES 6
-#endif
 // BP iteration 0 of one ray straight from its clipped + renormalised column, which the plane
 // sweep still holds in LDS when it stores it (mrf_bp.cu:88-177 with the prior in every voxel and
 // no messages yet: ONE occupancy for the whole ray, nothing to gather, nothing to read) -- the
@@ -304,14 +281,12 @@ __device__ __forceinline__ void first_sweep_messages(int count, int lane, float 
     // prior -- evaluated ONCE on the device (k_first_occupancy, the bits k_bp's own evaluation
     // gives) and handed in, instead of ~30 instructions per wavefront
     float carryT = 1.0f, carryC = 0.0f;
-#ifndef RN_FIRST_SWEEP_SCAN_PER_CHUNK
     // The transmittance scan of a chunk multiplies the SAME constant 1 - o in every valid lane,
     // and a lane's inclusive product depends on the lanes below it only: for every valid lane
     // it is the scan of a full chunk, whichever chunk -- scanned once per wavefront, the very
     // values (and the very carry, lane 63 of a full chunk) the per-chunk scans produce.
     const float incl_full = wave_scan_mul(1.0f - o_const);
     const float t_shift = wave_shift1(incl_full, 1.0f), t_carry = lane63(incl_full);
-#endif
     for (int base = 0; base < count; base += WAVE) {
         const int i = base + lane;
         const bool valid = i < count;
@@ -323,14 +298,8 @@ __device__ __forceinline__ void first_sweep_messages(int count, int lane, float 
             __builtin_nontemporal_store(sv, Sr_row + i);
         }
         const float o = valid ? o_const : 0.0f;
-#ifndef RN_FIRST_SWEEP_SCAN_PER_CHUNK
         const float T = carryT * t_shift;
         carryT = carryT * t_carry;
-#else
-        const float incl = wave_scan_mul(valid ? 1.0f - o : 1.0f);
-        const float T = carryT * wave_shift1(incl, 1.0f);
-        carryT = carryT * lane63(incl);
-#endif
         const float ts = T * sv;
         const float w = valid ? o * ts : 0.0f;
         const float inclC = wave_scan_add(w);
@@ -359,7 +328,7 @@ __device__ __forceinline__ void first_sweep_messages(int count, int lane, float 
 }
 
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
-__global__ __launch_bounds__(SWEEP_BLOCK, (SIM == 2 && MAPMODE >= 2 && NV >= 5 && NV <= RN_SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
+__global__ __launch_bounds__(SWEEP_BLOCK, (SIM == 2 && MAPMODE >= 2 && NV >= 5 && NV <= SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
 void k_sweep_map(
     Params p, int n, const int32_t *__restrict__ ray_idxs, FeatureViews fv,
     const float *__restrict__ P, const float *__restrict__ P_inv, const float *__restrict__ cc,
@@ -409,8 +378,6 @@ void k_sweep_map(
     int lane;
     int r = ray_of_wave<SWEEP_BLOCK, RN_XCD_CHUNK_SWEEP>(n, lane, xcd_chunk);
     if (r < 0) return;
-    RN_PHASE_DECL;
-    RN_PHASE_MARK(0);                      // (clock read only)
     if (order) r = uniform(order[r]);      // schedule only: which ray this wavefront takes
 
     float s[3], e[3];
@@ -451,11 +418,6 @@ void k_sweep_map(
             n_staged = (count + WAVE - 1) & ~(WAVE - 1);
         }
     }
-    RN_PHASE_MARK(1);                      // ray index + segment loads
-    if (RN_SWEEP_STOP == 1) {
-        if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
     if (SIM == 0) {
         for (int k = lane; k < p.D; k += WAVE) Sl[k] = S_in[(size_t)r * p.D + k];
     } else {
@@ -464,19 +426,9 @@ void k_sweep_map(
         else
             sweep_coop<NV, LPS, RESIDENT>(p, fv, fv_table, P, s, e, lane, Sl);
         wave_sync();
-        RN_PHASE_MARK(2);                  // projection + feature gathers + pair sums
-        if (RN_SWEEP_STOP == 12 || RN_SWEEP_STOP == 2) {
-            if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            return;
-        }
         softmax_column<RESIDENT>(p.D, lane, Sl);
     }
     wave_sync();
-    RN_PHASE_MARK(3);                      // softmax
-    if (RN_SWEEP_STOP == 3) {
-        if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
 
     if (MAPMODE == 0) {
         for (int k = lane; k < p.D; k += WAVE) S_planes[(size_t)r * p.D + k] = Sl[k];
@@ -522,19 +474,10 @@ void k_sweep_map(
     if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the voxel row
     // MAPMODE 2 = the resident path: value-only divisions through the hardware reciprocal
     // (the plane index walk inside stays IEEE); MAPMODE 1 = K6 / K11, reference arithmetic
-#ifdef RN_MAP_WALK      // A/B knob: the reference's walk and IEEE division in the resident path too
-    constexpr bool MAP_TABLE = false;
-#else
     constexpr bool MAP_TABLE = RESIDENT;
-#endif
     const float srsum =
         map_planes_to_voxels<PACKED, RESIDENT, PACKED, MAP_TABLE>(p, axes, vrow, count, s, e, Sl,
                                                                   vals, lane, n_staged, pos);
-    RN_PHASE_MARK(4);                      // planes -> voxels
-    if (RN_SWEEP_STOP == 4) {
-        if (lane == 0) out[0] = srsum;
-        return;
-    }
     if (MAPMODE == 1) {
         for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
     } else {
@@ -546,10 +489,6 @@ void k_sweep_map(
             sum += v;
         }
         sum = __builtin_amdgcn_rcpf(wave_sum(sum));
-        if (RN_SWEEP_STOP == 45) {
-            if (lane == 0) out[0] = sum;
-            return;
-        }
         if (MAPMODE == 3) {
             first_sweep_messages(count, lane, vals, sum, vals + p.M, vals + 2 * p.M, o_first, out,
                                  msgs_out + (size_t)r * p.M);
@@ -560,9 +499,5 @@ void k_sweep_map(
                 __builtin_nontemporal_store(vals[i] * sum, out + i);
         }
     }
-    RN_PHASE_MARK(5);                      // clip + renormalise + store
-#ifdef RN_PHASE_TIMERS
-    if (ph_on && lane == 0) atomicAdd(&g_phase[15], 1ull);
-#endif
 }
 

@@ -42,6 +42,26 @@ def test_no_timing_only_branches_in_the_product_sources():
             assert "RN_EXP" not in src and "wrong results" not in src.lower(), f
 
 
+def test_the_only_build_switches_are_the_exact_arithmetic_ones():
+    """Round 6: every A/B switch of the laboratory (phase-stop instrumentation, literal forms kept
+    next to their exact shortcuts, tile / block / chunk knobs) left the product sources as
+    tools/experiments/r06_lab_switches_removed.patch; what may still be conditional is the
+    exact-arithmetic build tests/test_exact_build_gpu.py keeps under test and the build tag."""
+    import re
+    csrc = os.path.join(REPO, "raynet_amd", "csrc")
+    allowed = {"RN_EXACT_OCC_EXP", "RN_EXACT_SOFTMAX_EXP", "RN_EXACT_BP_MATH", "RN_BUILD_EXTRA"}
+    count = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h", ".inl")):
+            continue
+        for line in open(os.path.join(csrc, f)):
+            if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", line):
+                count += 1
+                names = set(re.findall(r"\bRN_[A-Z0-9_]+", line))
+                assert names and names <= allowed, (f, line)
+    assert count <= 15, count
+
+
 def test_no_device_is_an_error_not_a_fallback():
     """Without a GPU the product refuses to run (there is no CPU route)."""
     import torch
