@@ -91,6 +91,9 @@ typedef struct {
                                1 on, 2 (default) when the scatter runs at level 1 [RAYNET_HIP_OVERLAP] */
     int32_t generic_sweep;  /* != 0: the reference-order plane sweep even for F = 32
                                [RAYNET_HIP_GENERIC_SWEEP] */
+    int32_t sweep_rays_per_wave;  /* rays one wavefront of the cooperative plane sweep takes: 0
+                               (default) by D -- 4 for D <= 16, 2 for D <= 32, else 1; 1: always one
+                               (the same bits, slower for D <= 32) [RAYNET_HIP_SWEEP_RAYS_PER_WAVE] */
 } rn_options;
 int rn_get_options(const rn_ctx *ctx, rn_options *out);
 /* also restarts the adaptive scatter (rn_scatter_reset) */

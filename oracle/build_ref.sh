@@ -29,4 +29,6 @@ gcc -O2 -fPIC -shared -ffp-contract=off -fno-fast-math -I"$INC" \
     "$OUT/ray_tracing.c" -o "$OUT/ray_tracing$SUFFIX" -lm
 rm -f "$OUT/ray_tracing.c"   # keep only the binary
 echo "built $OUT/ray_tracing$SUFFIX"
-$PY "$HERE/build_ref_cu.py"
+# the reference-kernel code objects are test infrastructure: a compiler that is missing or refuses one
+# of them must not fail the product build (the tests that need them skip without the manifest)
+$PY "$HERE/build_ref_cu.py" || echo "build_ref: reference .cu code objects NOT built (tests/test_reference_kernels.py will skip)" >&2

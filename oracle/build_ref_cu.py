@@ -148,7 +148,7 @@ def main():
                 fh.write(substituted(shape))
             for variant, extra in (("fma", []), ("nofma", ["-ffp-contract=off"])):
                 co = os.path.join(OUT, "raynet_ref_%s_%s.co" % (name, variant))
-                cmd = ["hipcc", "-x", "hip", "-include", "hip/hip_runtime.h",
+                cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "-include", "hip/hip_runtime.h",
                        "--offload-arch=gfx950", "--cuda-device-only", "--no-gpu-bundle-output",
                        "-O3", "-w"] + extra + [cu, "-o", co]
                 subprocess.check_call(cmd)

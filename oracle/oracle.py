@@ -119,6 +119,13 @@ class Oracle(object):
         see raynet_oracle.c.  Off by default."""
         _load().rno_set_robust_messages(1 if on else 0)
 
+    @staticmethod
+    def set_private_accumulators(on):
+        """Process-wide: a multi-threaded fused_bp sums every thread's messages in a private copy
+        of the accumulator (merged at the end) instead of `omp atomic` adds into the caller's one
+        array; see raynet_oracle.c.  Off by default."""
+        _load().rno_set_private_accumulators(1 if on else 0)
+
     # -- a1 ---------------------------------------------------------------
     def sample(self, ray_idxs, P_inv, center):
         ray_idxs = _i32(ray_idxs)

@@ -32,9 +32,11 @@
  *   rno_planes_to_voxels  the reference's NumPy `li` / `li_2` mappings
  *   rno_bp_ray / rno_depth_ray   the reference's mrf_np.py, both message forms on the small
  *                         scenes; the robust form on the saturated 96,000-ray scene
- *   rno_similarities      PARITY UNPINNED: the reference has only a PyCUDA and a TensorFlow
- *                         implementation of the plane sweep, neither runnable here, and no
- *                         test of it; cross-checked against the .cu text run on the host
+ *   rno_similarities      the reference's own batch_compute_similarities, its .cu text compiled
+ *                         unchanged for gfx950 (oracle/build_ref_cu.py) and run on an MI355X:
+ *                         fixture tests/golden/ref_cu_gfx950.npz, <= 1e-7
+ *                         (tests/test_reference_kernels.py); its geometry also by the reference's
+ *                         NumPy `project` (tests/test_projection_reference.py)
  *   rno_fused_bp / _depth compositions of the above
  *
  * Decisions where the reference's flavours disagree:
@@ -593,26 +595,54 @@ static int prefix_ray(const rno_config *c, int ray_idx, const float *features,
     return count;
 }
 
+/* Multi-threaded K1: where the threads' messages are summed.  0 (default): into the caller's ONE
+ * accumulator with `omp atomic` adds, the way the reference's kernel adds into its one array
+ * (mrf_bp.cu:170-176) -- its cache lines bounce between the cores.  1: every thread adds into a
+ * private zero-started copy, the copies are summed into the caller's array at the end (what an
+ * "all host cores" CPU figure should be measured with: bench.py's cpu_baseline reports both). */
+static int g_private_accumulators = 0;
+void rno_set_private_accumulators(int on) { g_private_accumulators = on; }
+
 /* K1 (raynet_fp.py:106-149) */
 void rno_fused_bp(const rno_config *c, int n, const int32_t *ray_idxs, const float *features,
                   const float *P, const float *P_inv, const float *center,
                   const float *voxel_grid, int32_t *rvi, int32_t *rvc, float *S_voxel,
                   const float *acc_in, float *msgs, float *acc_out, int threads) {
     threads = pick_threads(threads);
+    const size_t G = (size_t)c->grid[0] * c->grid[1] * c->grid[2];
+    const int private_acc = g_private_accumulators && threads > 1;
+    float **parts = private_acc ? (float **)calloc((size_t)threads, sizeof(float *)) : NULL;
 #pragma omp parallel num_threads(threads)
     {
         float *Sr = (float *)malloc(sizeof(float) * c->M);
         float *Sd = (float *)malloc(sizeof(float) * c->D);
+        float *mine = acc_out;
+#ifdef _OPENMP
+        if (private_acc) mine = parts[omp_get_thread_num()] = (float *)calloc(G, sizeof(float));
+#endif
 #pragma omp for schedule(dynamic, 64)
         for (int r = 0; r < n; r++) {
             int32_t *row = rvi + (size_t)3 * c->M * r;
             float *sv = S_voxel + (size_t)c->M * r;
             float *m = msgs + (size_t)c->M * r;
             rvc[r] = prefix_ray(c, ray_idxs[r], features, P, P_inv, center, voxel_grid, row, sv, Sd);
-            rno_bp_ray(c, sv, row, rvc[r], acc_in, m, acc_out, m, Sr, threads > 1);
+            rno_bp_ray(c, sv, row, rvc[r], acc_in, m, mine, m, Sr, threads > 1 && !private_acc);
         }
         free(Sr);
         free(Sd);
+        if (private_acc) {
+#pragma omp for schedule(static)
+            for (size_t i = 0; i < G; i++) {
+                float sum = 0.0f;
+                for (int t = 0; t < threads; t++)
+                    if (parts[t]) sum += parts[t][i];
+                acc_out[i] += sum;
+            }
+        }
+    }
+    if (private_acc) {
+        for (int t = 0; t < threads; t++) free(parts[t]);
+        free(parts);
     }
 }
 

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # RAYNET_HIP_LIB: another BUILD of the same library (a variant from build(extra_flags=..., out=...));
 # its rn_version() says what it was built with
-LIB_PATH = os.environ.get("RAYNET_HIP_LIB") or os.path.join(CSRC, "libraynet_hip.so")
+ENV_LIB = os.environ.get("RAYNET_HIP_LIB") or None     # read ONCE: the path and every test on it
+LIB_PATH = ENV_LIB or os.path.join(CSRC, "libraynet_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "raynet_hip.h")
 
 HIPCC_FLAGS = [
@@ -39,11 +40,14 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
             os.path.join(CSRC, "raynet_prepare.inl"), os.path.join(CSRC, "raynet_mrf.inl"),
             os.path.join(CSRC, "raynet_train.inl"), os.path.join(CSRC, "raynet_eval.inl"), HEADER]
     extra = list(extra_flags) + os.environ.get("RAYNET_HIPCC_EXTRA", "").split()
-    if out is None and os.environ.get("RAYNET_HIP_LIB"):
+    if out is None and ENV_LIB:
         # RAYNET_HIP_LIB names ANOTHER build of the library (a variant somebody made on purpose):
         # it is loaded as it is and never rebuilt with the default flags over its path -- an A/B
         # run would then test the default build without saying so.  The in-tree path
         # is the only implicit build target.
+        if force or extra:
+            raise RaynetHipError("RAYNET_HIP_LIB=%s is loaded as it is: force / extra flags (%s) "
+                                 "need an explicit `out`" % (LIB_PATH, " ".join(extra)))
         if not os.path.exists(LIB_PATH):
             raise RaynetHipError("RAYNET_HIP_LIB=%s does not exist" % LIB_PATH)
         return LIB_PATH
@@ -76,7 +80,7 @@ class Options(ctypes.Structure):
     # rn_options (include/raynet_hip.h)
     _fields_ = [("scatter_mode", ctypes.c_int32), ("box_level", ctypes.c_int32),
                 ("box_pin", ctypes.c_int32), ("overlap", ctypes.c_int32),
-                ("generic_sweep", ctypes.c_int32)]
+                ("generic_sweep", ctypes.c_int32), ("sweep_rays_per_wave", ctypes.c_int32)]
 
 
 class ScenePlan(ctypes.Structure):

@@ -238,6 +238,7 @@ struct rn_ctx {
     bool have_axes;
     int scatter_mode;     // rn_options: -1 by row layout (default), 0 slab, 2 LDS box
     int generic_sweep;    // rn_options: reference-order plane sweep even for F = 32
+    int sweep_rpw;        // rn_options.sweep_rays_per_wave: 0 by D, 1 one ray per wavefront
     // LDS-box scatter: level in use (launch_bp), {chunks, overflowed chunks} of the previous
     // launches on the device and its pinned host mirror
     int box_level, box_level0;
@@ -284,6 +285,9 @@ struct rn_ctx {
     int prof_cap, prof_n;
     hipEvent_t *prof_ev;      // 2 * prof_cap
     int32_t *prof_id, *prof_rays;
+    // a failed opt-in to more than 64 KB of dynamic LDS (launch_sweep_t), reported by the launch check
+    hipError_t lds_optin_error;
+    size_t lds_optin_bytes;
     char err[512];
 };
 
@@ -327,6 +331,13 @@ int fail(rn_ctx *ctx, int code, const char *fmt, ...) {
 #define RN_LAUNCH_CHECK(ctx)                                                           \
     do {                                                                               \
         hipError_t e_ = hipGetLastError();                                             \
+        if ((ctx)->lds_optin_error != hipSuccess) {                                    \
+            const hipError_t o_ = (ctx)->lds_optin_error;                              \
+            (ctx)->lds_optin_error = hipSuccess;                                       \
+            return fail(ctx, RN_ERR_HIP, "the plane sweep's opt-in to %zu bytes of LDS "  \
+                        "(hipFuncSetAttribute) failed: %s; its launch: %s",            \
+                        (ctx)->lds_optin_bytes, hipGetErrorString(o_), hipGetErrorString(e_)); \
+        }                                                                              \
         if (e_ != hipSuccess)                                                          \
             return fail(ctx, RN_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
     } while (0)
@@ -344,6 +355,11 @@ inline size_t sweep_lds(const Params &p, int rows = 1) {
                             (size_t)SWEEP_WAVES * (p.D + (size_t)rows * p.M));
 }
 inline int sweep_blocks(int n) { return (n + SWEEP_WAVES - 1) / SWEEP_WAVES; }
+// rays a wavefront of the cooperative sweep takes (k_sweep_map_packed for 2 / 4)
+inline int sweep_rays_per_wave(const rn_ctx *ctx) {
+    if (ctx->sweep_rpw == 1) return 1;
+    return ctx->p.D <= 16 ? 4 : ctx->p.D <= 32 ? 2 : 1;
+}
 
 // floats of one resident (bricked) accumulator: every axis padded to a multiple of 4
 inline int64_t acc_floats(const rn_ctx *ctx) {
@@ -355,6 +371,17 @@ FeatureViews stacked_views(const Params &p, const float *features) {
     const size_t dim = (size_t)p.Hf * p.Wf * p.F;
     for (int v = 0; v < MAX_VIEWS; v++) fv.v[v] = v < p.N ? features + dim * v : nullptr;
     return fv;
+}
+
+inline void lds_opt_in(rn_ctx *ctx, const void *kernel, size_t lds, size_t &granted) {
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+        granted = lds;
+    } else {
+        (void)hipGetLastError();
+        ctx->lds_optin_error = e;
+        ctx->lds_optin_bytes = lds;
+    }
 }
 
 struct SweepArgs {
@@ -381,9 +408,11 @@ template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
 void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
     ProfScope prof(ctx, RN_K_SWEEP_MAP, a.n * a.n_images, st);
     const size_t lds = sweep_lds(ctx->p, MAPMODE == 3 ? 3 : 1);
-    if (lds > 64 * 1024)        // (gfx950 has 160 KB per CU; beyond 64 KB a kernel has to say so)
-        (void)hipFuncSetAttribute((const void *)k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // gfx950 has 160 KB per CU; beyond 64 KB a kernel has to say so -- once per instantiation and
+    // size (one process drives one GPU), and a refusal is kept for the launch check to report
+    static size_t granted = 64 * 1024;
+    if (lds > granted)
+        lds_opt_in(ctx, (const void *)k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>, lds, granted);
     hipLaunchKernelGGL((k_sweep_map<SIM, NV, LPS, MAPMODE, PACKED>),
                        dim3(sweep_blocks(a.n), a.n_images), dim3(SWEEP_BLOCK), lds, st,
                        ctx->p, a.n, a.ray_idxs, a.fv, a.P, a.P_inv, a.cc, a.starts, a.ends, a.S_in,
@@ -393,7 +422,31 @@ void launch_sweep_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
                        a.zero ? (int)(acc_floats(ctx) / 4) : 0, a.xcd_chunk);
 }
 
-// pick the plane-sweep flavour: cooperative for F=32 and 2..9 views, generic otherwise
+// k_sweep_map_packed: RPW rays per wavefront (D <= 64 / RPW)
+inline size_t sweep_lds_packed(const Params &p, int rows, int rpw) {
+    return sizeof(float) * ((size_t)((p.gx + p.gy + p.gz + 3) & ~3) + (size_t)((p.D + 4) & ~3) +
+                            (size_t)SWEEP_WAVES * ((size_t)rpw * p.D + (size_t)rows * p.M));
+}
+template <int NV, int LPS, int MAPMODE, bool PACKED, int RPW>
+void launch_sweep_packed_t(rn_ctx *ctx, const SweepArgs &a, hipStream_t st) {
+    ProfScope prof(ctx, RN_K_SWEEP_MAP, a.n * a.n_images, st);
+    const size_t lds = sweep_lds_packed(ctx->p, MAPMODE == 3 ? 3 : 1, RPW);
+    static size_t granted = 64 * 1024;
+    if (lds > granted)
+        lds_opt_in(ctx, (const void *)k_sweep_map_packed<NV, LPS, MAPMODE, PACKED, RPW>, lds, granted);
+    const int nwaves = (a.n + RPW - 1) / RPW;
+    hipLaunchKernelGGL((k_sweep_map_packed<NV, LPS, MAPMODE, PACKED, RPW>),
+                       dim3(sweep_blocks(nwaves), a.n_images), dim3(SWEEP_BLOCK), lds, st,
+                       ctx->p, a.n, a.ray_idxs, a.fv, a.P, a.P_inv, a.cc, a.starts, a.ends,
+                       ctx->axes, a.vox, a.rvc, a.S_planes, a.S_voxel, a.depth_from_planes,
+                       a.points, a.order, a.fv_table, a.cam_stride, a.rows_per_image, a.seg,
+                       a.msgs_out, a.prior, reinterpret_cast<float4 *>(a.zero),
+                       a.zero ? (int)(acc_floats(ctx) / 4) : 0,
+                       a.xcd_chunk > 0 ? (a.xcd_chunk + RPW - 1) / RPW : 0);
+}
+
+// pick the plane-sweep flavour: cooperative for F=32 and 2..9 views (two / four rays per
+// wavefront for D <= 32 / 16 unless rn_options.sweep_rays_per_wave says 1), generic otherwise
 template <int MAPMODE, bool PACKED>
 void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream_t st) {
     const Params &p = ctx->p;
@@ -402,10 +455,16 @@ void launch_sweep(rn_ctx *ctx, const SweepArgs &a, bool have_features, hipStream
         return;
     }
     if (p.F == 32 && !ctx->generic_sweep) {
+        const int rpw = sweep_rays_per_wave(ctx);
         switch (p.N) {
 #define RN_CASE(NV_)                                                  \
     case NV_:                                                         \
-        launch_sweep_t<2, NV_, 8 / SWEEP_V4, MAPMODE, PACKED>(ctx, a, st);       \
+        if (rpw == 4)                                                 \
+            launch_sweep_packed_t<NV_, 8 / SWEEP_V4, MAPMODE, PACKED, 4>(ctx, a, st);   \
+        else if (rpw == 2)                                            \
+            launch_sweep_packed_t<NV_, 8 / SWEEP_V4, MAPMODE, PACKED, 2>(ctx, a, st);   \
+        else                                                          \
+            launch_sweep_t<2, NV_, 8 / SWEEP_V4, MAPMODE, PACKED>(ctx, a, st);       \
         return;
             RN_CASE(2) RN_CASE(3) RN_CASE(4) RN_CASE(5) RN_CASE(6) RN_CASE(7) RN_CASE(8) RN_CASE(9)
 #undef RN_CASE
@@ -696,6 +755,8 @@ int rn_create(const rn_config *cfg, rn_ctx **out) {
     const char *ov = getenv("RAYNET_HIP_OVERLAP");
     ctx->overlap = ov ? (atoi(ov) != 0 ? 1 : 0) : 2;
     ctx->generic_sweep = getenv("RAYNET_HIP_GENERIC_SWEEP") != nullptr;
+    const char *rw = getenv("RAYNET_HIP_SWEEP_RAYS_PER_WAVE");
+    ctx->sweep_rpw = rw && atoi(rw) == 1 ? 1 : 0;
     ctx->prof_mask = ~0u;
     if (sweep_lds(p) > 160 * 1024) {      // before anything is allocated
         delete ctx;
@@ -745,19 +806,22 @@ int rn_get_options(const rn_ctx *ctx, rn_options *out) {
     out->box_pin = ctx->box_pin ? 1 : 0;
     out->overlap = ctx->overlap;
     out->generic_sweep = ctx->generic_sweep;
+    out->sweep_rays_per_wave = ctx->sweep_rpw;
     return RN_OK;
 }
 
 int rn_set_options(rn_ctx *ctx, const rn_options *opt) {
     if (!ctx || !opt) return RN_ERR_INVALID;
     if ((opt->scatter_mode != -1 && opt->scatter_mode != 0 && opt->scatter_mode != 2) ||
-        opt->box_level < 0 || opt->box_level > 2 || opt->overlap < 0 || opt->overlap > 2)
+        opt->box_level < 0 || opt->box_level > 2 || opt->overlap < 0 || opt->overlap > 2 ||
+        (opt->sweep_rays_per_wave != 0 && opt->sweep_rays_per_wave != 1))
         return fail(ctx, RN_ERR_INVALID, "rn_set_options: value out of range");
     ctx->scatter_mode = opt->scatter_mode;
     ctx->box_level = ctx->box_level0 = opt->box_level;
     ctx->box_pin = opt->box_pin != 0;
     ctx->overlap = opt->overlap;
     ctx->generic_sweep = opt->generic_sweep != 0;
+    ctx->sweep_rpw = opt->sweep_rays_per_wave;
     ctx->box_obs[0] = ctx->box_obs[1] = 0;
     ctx->box_probe = BOX_PROBE_LAUNCHES;
     ctx->box_rebase = ctx->box_probe_used;

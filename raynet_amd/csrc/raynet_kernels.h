@@ -409,10 +409,11 @@ __device__ __forceinline__ float sweep_round(const float *const (&vbase)[NV], co
 // RPW rays share the wavefront (sweep_coop): sample j is plane j % DPAD of ray j / DPAD, DPAD =
 // 64 / RPW; a load round's 64 / LPS samples never straddle two rays (DPAD >= 16), so the held
 // vector of view 0 is ref[ray of the round].  `live` = planes of a ray that exist (D, or what is
-// left of D in this chunk when RPW = 1), `nrays` = rays of this wavefront that exist: rounds whose
-// samples are all beyond either are skipped (wave-uniform) -- the cost of a sweep is proportional
-// to D as the reference's loop is (feature_similarities.cu:84), not to 64.
-template <int NV, int LPS, int V4, bool REF_HELD, int RPW>
+// left of D in this chunk when RPW = 1), `nrays` = rays of this wavefront that exist.  PARTIAL: rounds
+// whose samples are all beyond either are skipped (wave-uniform branches) -- the cost of a sweep is
+// proportional to D as the reference's loop is (feature_similarities.cu:84), not to 64; a full
+// chunk takes the branch-free instantiation, whose loads the compiler schedules across rounds.
+template <int NV, int LPS, int V4, bool REF_HELD, int RPW, bool PARTIAL>
 __device__ __forceinline__ float sweep_rounds(const float *const (&vbase)[NV], const int (&offb)[NV],
                                               int sub, int part, unsigned part_bytes,
                                               const float2v (&ref)[RPW][2 * V4], int live, int nrays,
@@ -434,7 +435,7 @@ __device__ __forceinline__ float sweep_rounds(const float *const (&vbase)[NV], c
 #pragma unroll
         for (int t = 0; t < LPS / 2; t++) {
             const int first = (2 * t) * SPL;             // first sample of the pair of rounds
-            if (first % DPAD >= live || first / DPAD >= nrays) continue;
+            if (PARTIAL && (first % DPAD >= live || first / DPAD >= nrays)) continue;
             const float2v(&rf)[2 * V4] = ref[RPW == 1 ? 0 : first / DPAD];
             const float a0 = sweep_round<NV, V4, REF_HELD>(vbase, offb, first + sub, part_bytes, rf);
             const float a1 = sweep_round<NV, V4, REF_HELD>(vbase, offb, first + SPL + sub, part_bytes, rf);
@@ -451,7 +452,7 @@ __device__ __forceinline__ float sweep_rounds(const float *const (&vbase)[NV], c
 #pragma unroll
         for (int it = 0; it < LPS; it++) {
             const int first = it * SPL;
-            if (first % DPAD >= live || first / DPAD >= nrays) continue;
+            if (PARTIAL && (first % DPAD >= live || first / DPAD >= nrays)) continue;
             float acc = sweep_round<NV, V4, REF_HELD>(vbase, offb, first + sub, part_bytes,
                                                       ref[RPW == 1 ? 0 : first / DPAD]);
             if (LPS >= 2) RN_ADD_DPP(acc, acc, acc, RN_DPP_XOR1);
@@ -543,10 +544,13 @@ __device__ __forceinline__ void sweep_coop(const Params &p, const FeatureViews &
         float mine = 0.0f;
         int mine_round;         // which load round's sample this lane ends up holding
         const int live = RPW == 1 ? p.D - base : p.D;
-        if (ref_held)
-            mine = sweep_rounds<NV, LPS, V4, true, RPW>(vbase, offb, sub, part, part_bytes, ref, live, nrays, mine_round);
+        const bool full = live >= DPAD && nrays == RPW;
+        if (ref_held && full)
+            mine = sweep_rounds<NV, LPS, V4, true, RPW, false>(vbase, offb, sub, part, part_bytes, ref, live, nrays, mine_round);
+        else if (ref_held)
+            mine = sweep_rounds<NV, LPS, V4, true, RPW, true>(vbase, offb, sub, part, part_bytes, ref, live, nrays, mine_round);
         else
-            mine = sweep_rounds<NV, LPS, V4, false, RPW>(vbase, offb, sub, part, part_bytes, ref, live, nrays, mine_round);
+            mine = sweep_rounds<NV, LPS, V4, false, RPW, true>(vbase, offb, sub, part, part_bytes, ref, live, nrays, mine_round);
         const int j = mine_round * SPL + sub;           // the sample this lane holds
         const int k = RPW == 1 ? base + j : j % DPAD;
         const int q = RPW == 1 ? 0 : j / DPAD;

@@ -327,6 +327,98 @@ __device__ __forceinline__ void first_sweep_messages(int count, int lane, float 
     }
 }
 
+// MAPMODE 0's tail for one ray: the plane column out, and K10's points / first arg-max plane /
+// distance to the camera (similarities.py:199-227)
+__device__ __forceinline__ void planes_out(const Params &p, int r, const float s[3], const float e[3],
+                                           const float *Sl, int lane, const float *__restrict__ cc,
+                                           float *S_planes, float *depth_from_planes, float *points) {
+    for (int k = lane; k < p.D; k += WAVE) S_planes[(size_t)r * p.D + k] = Sl[k];
+    if (!depth_from_planes) return;
+    float best = -INFINITY;
+    int best_k = 0;
+    for (int k = lane; k < p.D; k += WAVE) {
+        float pt[3];
+        plane_point(s, e, k, p.D, pt);
+        reinterpret_cast<float4 *>(points)[(size_t)r * p.D + k] = make_float4(pt[0], pt[1], pt[2], 1.0f);
+        if (Sl[k] > best) {
+            best = Sl[k];
+            best_k = k;
+        }
+    }
+    // first maximum: larger value wins, then smaller index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int ok = __shfl_xor(best_k, o);
+        if (ob > best || (ob == best && ok < best_k)) {
+            best = ob;
+            best_k = ok;
+        }
+    }
+    if (lane == 0) {
+        float pt[3];
+        plane_point(s, e, best_k, p.D, pt);
+        float sum = 0.0f;
+        for (int i = 0; i < 3; i++) {
+            const float d = pt[i] - cc[i];
+            sum += d * d;
+        }
+        depth_from_planes[r] = sqrtf(sum);
+    }
+}
+
+// MAPMODE 1 / 2 / 3's tail for one ray: planes -> voxels from the softmaxed column Sl, then the
+// normalised column (1), clip + renormalise (2), and BP iteration 0's messages (3)
+template <int MAPMODE, bool PACKED>
+__device__ __forceinline__ void voxels_out(const Params &p, int r, int count, int n_staged,
+                                           const float s[3], const float e[3], const float *Sl,
+                                           float *vals, const float *axes, const float *pos,
+                                           const int32_t *__restrict__ vrow, float *S_voxel,
+                                           float *msgs_out, float o_first, int lane) {
+    constexpr bool RESIDENT = MAPMODE >= 2;
+    float *out = S_voxel + (size_t)r * p.M;
+    if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the voxel row
+    // MAPMODE 2 = the resident path: value-only divisions through the hardware reciprocal
+    // (the plane index walk inside stays IEEE); MAPMODE 1 = K6 / K11, reference arithmetic
+    constexpr bool MAP_TABLE = RESIDENT;
+    const float srsum =
+        map_planes_to_voxels<PACKED, RESIDENT, PACKED, MAP_TABLE>(p, axes, vrow, count, s, e, Sl,
+                                                                  vals, lane, n_staged, pos);
+    if (MAPMODE == 1) {
+        for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
+    } else {
+        float sum = 0.0f;
+        const float rs = __builtin_amdgcn_rcpf(srsum);
+        for (int i = lane; i < count; i += WAVE) {
+            const float v = clampf(vals[i] * rs, (float)1e-5, (float)(1 - 1e-5));
+            vals[i] = v;
+            sum += v;
+        }
+        sum = __builtin_amdgcn_rcpf(wave_sum(sum));
+        if (MAPMODE == 3) {
+            first_sweep_messages(count, lane, vals, sum, vals + p.M, vals + 2 * p.M, o_first, out,
+                                 msgs_out + (size_t)r * p.M);
+        } else {
+            // streamed out, read again only by later kernels: keep it out of the L2 the feature
+            // gathers live in
+            for (int i = lane; i < count; i += WAVE)
+                __builtin_nontemporal_store(vals[i] * sum, out + i);
+        }
+    }
+}
+
+// the ray's packed voxel ids straight from global memory into an LDS row (LDS-DMA: no staging
+// registers; LDS address = wave-uniform base + 4 * lane, which is the row's own layout)
+__device__ __forceinline__ int stage_voxel_row(const Params &p, const int32_t *__restrict__ vrow,
+                                               int count, float *vals, int lane) {
+    typedef const __attribute__((address_space(1))) void *gptr;
+    typedef __attribute__((address_space(3))) void *lptr;
+    for (int c = 0; c < count; c += WAVE)
+        if (c + lane < p.M)
+            __builtin_amdgcn_global_load_lds((gptr)(vrow + c + lane), (lptr)(vals + c), 4, 0, RN_SWEEP_LIST_CPOL);
+    return (count + WAVE - 1) & ~(WAVE - 1);
+}
+
 template <int SIM, int NV, int LPS, int MAPMODE, bool PACKED>
 __global__ __launch_bounds__(SWEEP_BLOCK, (SIM == 2 && MAPMODE >= 2 && NV >= 5 && NV <= SWEEP_UNROLL2_MAX_VIEWS ? RN_SWEEP_MIN_WAVES : 1))
 void k_sweep_map(
@@ -397,10 +489,9 @@ void k_sweep_map(
     }
 
     // The ray's voxel row is needed only after the sweep -- three dependent ~1.5k-cycle loads
-    // later if fetched there (tools/phase_timers.py).  Its count is fetched with the segment
-    // and the packed ids go straight from global memory into this wave's vals[] row (unused
-    // until the mapping) with LDS-DMA loads: no staging registers, and the sweep covers the
-    // latency.  LDS address = wave-uniform base + 4 * lane, which is the row's own layout.
+    // later if fetched there.  Its count is fetched with the segment and the packed ids go
+    // straight into this wave's vals[] row (unused until the mapping): the sweep covers the
+    // latency.
     int count = 0, n_staged = 0;
     const int32_t *vrow = vox + (size_t)r * p.M * (PACKED ? 1 : 3);
     if (MAPMODE != 0) {
@@ -409,14 +500,7 @@ void k_sweep_map(
         // message, mrf_np.py:300, and their depth is that of voxel 0): no sweep for the rays
         // that miss the box (5 % of config 2's)
         if (RESIDENT && count <= 1) return;
-        if (PACKED) {
-            typedef const __attribute__((address_space(1))) void *gptr;
-            typedef __attribute__((address_space(3))) void *lptr;
-            for (int c = 0; c < count; c += WAVE)
-                if (c + lane < p.M)
-                    __builtin_amdgcn_global_load_lds((gptr)(vrow + c + lane), (lptr)(vals + c), 4, 0, RN_SWEEP_LIST_CPOL);
-            n_staged = (count + WAVE - 1) & ~(WAVE - 1);
-        }
+        if (PACKED) n_staged = stage_voxel_row(p, vrow, count, vals, lane);
     }
     if (SIM == 0) {
         for (int k = lane; k < p.D; k += WAVE) Sl[k] = S_in[(size_t)r * p.D + k];
@@ -430,74 +514,127 @@ void k_sweep_map(
     }
     wave_sync();
 
-    if (MAPMODE == 0) {
-        for (int k = lane; k < p.D; k += WAVE) S_planes[(size_t)r * p.D + k] = Sl[k];
-        if (depth_from_planes) {
-            // similarities.py:199-227: points, first arg-max plane, distance to the camera
-            float best = -INFINITY;
-            int best_k = 0;
-            for (int k = lane; k < p.D; k += WAVE) {
-                float pt[3];
-                plane_point(s, e, k, p.D, pt);
-                reinterpret_cast<float4 *>(points)[(size_t)r * p.D + k] =
-                    make_float4(pt[0], pt[1], pt[2], 1.0f);
-                if (Sl[k] > best) {
-                    best = Sl[k];
-                    best_k = k;
-                }
-            }
-            // first maximum: larger value wins, then smaller index
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(best, o);
-                const int ok = __shfl_xor(best_k, o);
-                if (ob > best || (ob == best && ok < best_k)) {
-                    best = ob;
-                    best_k = ok;
-                }
-            }
-            if (lane == 0) {
-                float pt[3];
-                plane_point(s, e, best_k, p.D, pt);
-                float sum = 0.0f;
-                for (int i = 0; i < 3; i++) {
-                    const float d = pt[i] - cc[i];
-                    sum += d * d;
-                }
-                depth_from_planes[r] = sqrtf(sum);
-            }
-        }
-        return;
-    }
-
-    float *out = S_voxel + (size_t)r * p.M;
-    if (PACKED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the voxel row
-    // MAPMODE 2 = the resident path: value-only divisions through the hardware reciprocal
-    // (the plane index walk inside stays IEEE); MAPMODE 1 = K6 / K11, reference arithmetic
-    constexpr bool MAP_TABLE = RESIDENT;
-    const float srsum =
-        map_planes_to_voxels<PACKED, RESIDENT, PACKED, MAP_TABLE>(p, axes, vrow, count, s, e, Sl,
-                                                                  vals, lane, n_staged, pos);
-    if (MAPMODE == 1) {
-        for (int i = lane; i < count; i += WAVE) out[i] = vals[i] / srsum;
-    } else {
-        float sum = 0.0f;
-        const float rs = __builtin_amdgcn_rcpf(srsum);
-        for (int i = lane; i < count; i += WAVE) {
-            const float v = clampf(vals[i] * rs, (float)1e-5, (float)(1 - 1e-5));
-            vals[i] = v;
-            sum += v;
-        }
-        sum = __builtin_amdgcn_rcpf(wave_sum(sum));
-        if (MAPMODE == 3) {
-            first_sweep_messages(count, lane, vals, sum, vals + p.M, vals + 2 * p.M, o_first, out,
-                                 msgs_out + (size_t)r * p.M);
-        } else {
-            // streamed out, read again only by later kernels: keep it out of the L2 the feature
-            // gathers live in
-            for (int i = lane; i < count; i += WAVE)
-                __builtin_nontemporal_store(vals[i] * sum, out + i);
-        }
-    }
+    if (MAPMODE == 0)
+        planes_out(p, r, s, e, Sl, lane, cc, S_planes, depth_from_planes, points);
+    else
+        voxels_out<MAPMODE, PACKED>(p, r, count, n_staged, s, e, Sl, vals, axes, pos, vrow, S_voxel,
+                                    msgs_out, o_first, lane);
 }
 
+// The cooperative sweep for D <= 32 (the reference's own default, scripts/arguments.py:154) and
+// D <= 16: RPW = 2 / 4 rays share a wavefront through projection, gathers, pair sums and softmax
+// -- lane l = plane l % DPAD of ray l / DPAD, every one of the 8 load rounds full of live samples
+// -- where one ray per wavefront would project 32 / 48 dead lanes and run 4 / 6 load rounds of
+// duplicates; the per-ray tail (planes -> voxels, clip, BP iteration 0: lanes over VOXELS) then
+// runs for the wavefront's rays one after the other.  Per (ray, plane) the arithmetic is the
+// instruction sequence of k_sweep_map: same bits (tests/test_packed_sweep_gpu.py).
+// Wavefront w takes rows RPW w .. RPW w + RPW - 1 of the launch.
+// Dynamic LDS: [axes][plane positions][per wave: RPW x D plane columns, M values (3 M for 3)]
+template <int NV, int LPS, int MAPMODE, bool PACKED, int RPW>
+__global__ __launch_bounds__(SWEEP_BLOCK)
+void k_sweep_map_packed(
+    Params p, int n, const int32_t *__restrict__ ray_idxs, FeatureViews fv,
+    const float *__restrict__ P, const float *__restrict__ P_inv, const float *__restrict__ cc,
+    const float *__restrict__ starts, const float *__restrict__ ends,
+    const float *__restrict__ axes_g, const int32_t *__restrict__ vox,
+    const int32_t *__restrict__ rvc, float *S_planes, float *S_voxel, float *depth_from_planes,
+    float *points, const int32_t *__restrict__ order, const float *const *__restrict__ fv_table,
+    int cam_stride, int64_t rows_per_image, const float *__restrict__ seg, float *msgs_out,
+    float o_first, float4 *zero_buf, int zero_count4, int xcd_chunk) {
+    static_assert(RPW == 2 || RPW == 4, "two or four rays per wavefront");
+    constexpr int DPAD = WAVE / RPW;
+    constexpr bool RESIDENT = MAPMODE >= 2;
+    const int nwaves = (n + RPW - 1) / RPW;      // wavefronts with a ray
+    if (MAPMODE == 3 && zero_buf && blockIdx.y == 0) {     // (as k_sweep_map)
+        const int nw = (nwaves + SWEEP_WAVES - 1) / SWEEP_WAVES * SWEEP_WAVES;
+        const int w = blockIdx.x * SWEEP_WAVES + (int)(threadIdx.x >> 6);
+        for (int i = w * WAVE + (int)(threadIdx.x & (WAVE - 1)); i < zero_count4; i += nw * WAVE)
+            zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (rows_per_image > 0) {       // blockIdx.y = reference image of a scene-wide launch
+        const int g = blockIdx.y;
+        P += (size_t)g * cam_stride;
+        P_inv += (size_t)g * cam_stride;
+        cc += (size_t)g * cam_stride;
+        fv_table += (size_t)g * p.N;
+        vox += (size_t)g * rows_per_image * p.M * (PACKED ? 1 : 3);
+        rvc += (size_t)g * rows_per_image;
+        S_voxel += (size_t)g * rows_per_image * p.M;
+        if (seg) seg += (size_t)g * rows_per_image * 8;
+        if (MAPMODE == 3) msgs_out += (size_t)g * rows_per_image * p.M;
+    }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int naxes = p.gx + p.gy + p.gz;
+    float *axes = smem;
+    const int wid = threadIdx.x >> 6;
+    float *pos = smem + ((naxes + 3) & ~3);
+    float *Sl = pos + ((p.D + 4) & ~3) + wid * (RPW * p.D + (MAPMODE == 3 ? 3 : 1) * p.M);
+    float *vals = Sl + RPW * p.D;
+    if (MAPMODE != 0) {
+        for (int i = threadIdx.x; i < naxes; i += SWEEP_BLOCK) axes[i] = axes_g[i];
+        if (RESIDENT)
+            for (int i = threadIdx.x; i <= p.D; i += SWEEP_BLOCK) pos[i] = 0.0f + i * p.plane_step;
+        __syncthreads();
+    }
+    int lane;
+    const int w = ray_of_wave<SWEEP_BLOCK, RN_XCD_CHUNK_SWEEP>(nwaves, lane, xcd_chunk);
+    if (w < 0) return;
+    const int r0 = w * RPW;
+    const int nrays = min(RPW, n - r0);
+    // this lane's ray (the lanes of a ray that does not exist shadow the wavefront's last one)
+    int r = r0 + min(lane / DPAD, nrays - 1);
+    if (order) r = order[r];               // schedule only
+    float s[3], e[3];
+    if (seg) {
+        const float4 a = reinterpret_cast<const float4 *>(seg)[2 * (size_t)r];
+        const float4 b = reinterpret_cast<const float4 *>(seg)[2 * (size_t)r + 1];
+        s[0] = a.x; s[1] = a.y; s[2] = a.z;
+        e[0] = b.x; e[1] = b.y; e[2] = b.z;
+    } else if (ray_idxs) {
+        sample_in_bbox(p, ray_idxs[r], P_inv, cc, s, e);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            s[i] = starts[3 * r + i];
+            e[i] = ends[3 * r + i];
+        }
+    }
+    int count = 0, n_staged = 0;
+    if (MAPMODE != 0) {
+        count = min(rvc[r], p.M);
+        // (as k_sweep_map: rays with <= 1 voxels are never read on the resident path)
+        if (RESIDENT && __all(count <= 1)) return;
+        // the first ray's voxel row on its way under the sweep; the others' when their turn comes
+        const int c0 = __builtin_amdgcn_readfirstlane(count);
+        const int rr = __builtin_amdgcn_readfirstlane(r);
+        if (PACKED && !(RESIDENT && c0 <= 1))
+            n_staged = stage_voxel_row(p, vox + (size_t)rr * p.M, c0, vals, lane);
+    }
+    sweep_coop<NV, LPS, RESIDENT, RPW>(p, fv, fv_table, P, s, e, lane, Sl, nrays);
+    wave_sync();
+    softmax_columns<RESIDENT, RPW>(p.D, lane, Sl);
+    wave_sync();
+    for (int q = 0; q < nrays; q++) {
+        // ray q's row, segment and count from its first lane into SGPRs: the tail is k_sweep_map's
+        const int rq = __builtin_amdgcn_readlane(r, q * DPAD);
+        float su[3], eu[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            su[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s[i]), q * DPAD));
+            eu[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e[i]), q * DPAD));
+        }
+        if (MAPMODE == 0) {
+            planes_out(p, rq, su, eu, Sl + q * p.D, lane, cc, S_planes, depth_from_planes, points);
+            continue;
+        }
+        const int cq = __builtin_amdgcn_readlane(count, q * DPAD);
+        if (RESIDENT && cq <= 1) continue;
+        const int32_t *vrow = vox + (size_t)rq * p.M * (PACKED ? 1 : 3);
+        if (PACKED && q > 0) {
+            wave_sync();                   // the previous ray's tail is done with the rows
+            n_staged = stage_voxel_row(p, vrow, cq, vals, lane);
+        }
+        voxels_out<MAPMODE, PACKED>(p, rq, cq, n_staged, su, eu, Sl + q * p.D, vals, axes, pos, vrow,
+                                    S_voxel, msgs_out, o_first, lane);
+    }
+}

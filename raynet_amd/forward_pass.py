@@ -333,8 +333,8 @@ class RayNetForwardPass(ForwardPass):
     ray_tile = property(lambda self: self.options.ray_tile,
                         lambda self, v: setattr(self, "options", self.options.replace(ray_tile=v)))
     deterministic = property(lambda self: self.options.deterministic,
-                             lambda self, v: setattr(self, "options",
-                                                     self.options.replace(deterministic=bool(v))))
+                             lambda self, v: setattr(self, "options", self.options.replace(
+                                 deterministic=None if v is None else bool(v))))
     @property
     def accumulator(self):
         """[gx][gy][gz] log-odds accumulator of the last pass (mrf_bp.cu:3-10 layout).  The
@@ -537,7 +537,7 @@ class RayNetForwardPass(ForwardPass):
                           "budget (%.1f GB); traversal and plane sweep are recomputed group by "
                           "group in every sweep" % (Vg, V, budget / 2 ** 30))
         rows_g = Vg * npad
-        fixed_pt = opt.deterministic and hasattr(ctx, "scene_bp_sweep_fixed")
+        fixed_pt = opt.fixed_point(plan["world"]) and hasattr(ctx, "scene_bp_sweep_fixed")
         prior = plan["prior"]
         plan.update(
             groups=[list(range(g, min(g + Vg, V))) for g in range(0, V, Vg)] if V else [], Vg=Vg,
@@ -613,7 +613,7 @@ class RayNetForwardPass(ForwardPass):
         plan = dict(key=key, ptrs=ptrs, scene=scene, cams=cams, prior=self._prior(), dirty=False,
                     cam_dev=cam_dev, views_of=views_of, lists=lists, bounds=bounds,
                     balance=balance, shards=shards, npad=npad, shared=shared,
-                    patch_rows=patch_rows, fast=None, direct=False,
+                    patch_rows=patch_rows, fast=None, direct=False, world=world,
                     along_rows=self._along_rows,
                     table=torch.tensor(ptrs, dtype=torch.int64).to(dev) if V else None)
         self._plan_buffers(ctx, plan, refs, old_bytes)

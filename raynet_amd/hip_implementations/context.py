@@ -153,7 +153,8 @@ class HipContext(object):
         o = _lib.Options()
         self._check(self.lib.rn_get_options(self._h, ctypes.byref(o)))
         return dict(scatter_mode=o.scatter_mode, box_level=o.box_level, box_pin=bool(o.box_pin),
-                    overlap=o.overlap, generic_sweep=bool(o.generic_sweep))
+                    overlap=o.overlap, generic_sweep=bool(o.generic_sweep),
+                    sweep_rays_per_wave=o.sweep_rays_per_wave)
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -53,7 +53,13 @@ class PathOptions:
     # ---- memory ---------------------------------------------------------------------------
     resident_gb: float = 0.0          # HBM budget of the resident schedule; 0: 90 % of what is free
     # ---- multi-GPU ------------------------------------------------------------------------
-    deterministic: bool = False       # 64-bit fixed-point sums: same bits for any run / rank count
+    deterministic: Optional[bool] = None   # 64-bit fixed-point sums: same bits for any run / rank
+    #                                   count.  None (default) = ON when the pass runs on more than
+    #                                   one rank -- the N-rank result then EQUALS the one-rank
+    #                                   fixed-point result bit for bit, which is what SURVEY.md 8(e)
+    #                                   asks of a sharded run (float sums only reach 32 ulp of the
+    #                                   largest accumulator, ~1e-3) -- and off on one GPU (+2.5 %);
+    #                                   True / False: as said, whatever the rank count
     shard: str = "voxels"             # "voxels": work-balanced cuts; "rays": equal ray counts
     shard_alpha: Optional[float] = None   # per-ray constant of the balance in units of the mean voxel
     #                                       count; None: derived from the shape (shard_alpha_for)
@@ -65,6 +71,8 @@ class PathOptions:
     box_pin: bool = False             # stay at box_level
     overlap: int = 2                  # second stream: 0 off, 1 on, 2 when the scatter runs at level 1
     generic_sweep: bool = False       # reference-order plane sweep even for F = 32 (tests)
+    sweep_rays_per_wave: int = 0      # cooperative sweep: 0 = by D (4 rays per wavefront for D <= 16, 2
+    #                                   for D <= 32, else 1), 1 = always one (same bits; A/B and tests)
 
     # environment variable -> (field, parser); overrides only
     ENV = {
@@ -75,7 +83,8 @@ class PathOptions:
         "RAYNET_CAPTURE": ("capture", lambda t: {"0": "off", "1": "on"}.get(str(t).strip(), str(t).strip())),
         "RAYNET_MAPS": ("maps", str),
         "RAYNET_RESIDENT_GB": ("resident_gb", float),
-        "RAYNET_DETERMINISTIC": ("deterministic", _flag),
+        "RAYNET_DETERMINISTIC": ("deterministic",
+                                 lambda t: None if str(t).strip().lower() == "auto" else _flag(t)),
         "RAYNET_SHARD": ("shard", str),
         "RAYNET_SHARD_ALPHA": ("shard_alpha", float),
         "RAYNET_EXCHANGE": ("exchange", str),
@@ -84,6 +93,7 @@ class PathOptions:
         "RAYNET_HIP_BOX_PIN": ("box_pin", _flag),
         "RAYNET_HIP_OVERLAP": ("overlap", lambda t: 1 if int(t) else 0),
         "RAYNET_HIP_GENERIC_SWEEP": ("generic_sweep", _flag),
+        "RAYNET_HIP_SWEEP_RAYS_PER_WAVE": ("sweep_rays_per_wave", int),
     }
 
     def __post_init__(self):
@@ -93,6 +103,7 @@ class PathOptions:
         assert self.exchange in ("allreduce", "reduce_scatter"), self.exchange
         assert self.scatter_mode in (-1, 0, 2) and self.box_level in (0, 1, 2)
         assert self.overlap in (0, 1, 2)
+        assert self.sweep_rays_per_wave in (0, 1), self.sweep_rays_per_wave
         assert self.maps in ("lease", "copy"), self.maps
         assert self.capture in ("auto", "on", "off"), self.capture
 
@@ -107,6 +118,10 @@ class PathOptions:
         kw.update({k: v for k, v in overrides.items() if v is not None})
         return cls(**kw)
 
+    def fixed_point(self, world):
+        """Whether a pass over `world` ranks sums in fixed point (`deterministic`, None = by world)."""
+        return bool(world > 1) if self.deterministic is None else bool(self.deterministic)
+
     def replace(self, **kw):
         d = {f.name: getattr(self, f.name) for f in fields(self)}
         d.update(kw)
@@ -118,9 +133,9 @@ class PathOptions:
         return d
 
     def context_options(self):
-        """The five values of rn_options."""
+        """The six values of rn_options."""
         return (int(self.scatter_mode), int(self.box_level), 1 if self.box_pin else 0,
-                int(self.overlap), 1 if self.generic_sweep else 0)
+                int(self.overlap), 1 if self.generic_sweep else 0, int(self.sweep_rays_per_wave))
 
     def __setattr__(self, name, value):
         object.__setattr__(self, name, value)

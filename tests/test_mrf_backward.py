@@ -82,3 +82,33 @@ def test_prior_gradient_matches_finite_differences(oracle_mod):
     fd = ((G * mb.forward(S, *args, gamma=gamma + h, planes=planes)).sum() -
           (G * mb.forward(S, *args, gamma=gamma - h, planes=planes)).sum()) / (2 * h)
     assert abs(fd - dgamma) < 1e-5 * max(1.0, abs(fd)), (fd, dgamma)
+
+
+@pytest.mark.parametrize("seed,iters", [(0, 3), (1, 3), (2, 1), (5, 2), (4, 0)])
+def test_analytic_backward_matches_an_independent_autograd_derivative(oracle_mod, seed, iters):
+    """The second derivative check (the reference differentiates its TF graph by autodiff,
+    tf_implementations/forward_backward_pass.py:194-246, mrf/mrf_tf.py:60-271; TF is absent): a
+    float64 torch restatement of that graph, differentiated by torch.autograd
+    (oracle/mrf_autograd.py), against the hand-derived reverse pass -- EVERY entry of dL/dS and
+    dL/dgamma, not a sample of finite differences."""
+    from oracle import mrf_autograd as ma
+    from oracle import mrf_backward as mb
+    o, vg, starts, ends, rvi, rvc, S, planes = make_problem(oracle_mod, seed=seed)
+    rng = np.random.default_rng(200 + seed)
+    G = rng.standard_normal((len(S), rvi.shape[1]))
+    gamma = 0.05
+    args = (vg, rvi, rvc, starts, ends, o.grid_shape)
+    out_a, dS_a, dgamma_a = ma.gradients(G, S, *args, gamma=gamma, iters=iters, planes=planes)
+    out_b = mb.forward(S, *args, gamma=gamma, iters=iters, planes=planes)
+    dS_b, prior_bar = mb.backward(G, S, *args, gamma=gamma, iters=iters, planes=planes, with_prior=True)
+    assert np.abs(out_a - out_b).max() < 1e-12
+    scale = np.abs(dS_b).max()
+    assert scale > 1e-3
+    assert np.abs(dS_a - dS_b).max() <= 1e-9 * scale
+    dgamma_b = prior_bar * (1.0 / gamma + 1.0 / (1.0 - gamma))
+    assert abs(dgamma_a - dgamma_b) <= 1e-9 * max(1.0, abs(dgamma_b))
+    # ... and with the plane indices derived in float64 by each side on its own
+    out_c, dS_c, _ = ma.gradients(G, S, *args, gamma=gamma, iters=iters)
+    dS_d = mb.backward(G, S, *args, gamma=gamma, iters=iters)
+    assert np.abs(out_c - mb.forward(S, *args, gamma=gamma, iters=iters)).max() < 1e-12
+    assert np.abs(dS_c - dS_d).max() <= 1e-9 * max(scale, np.abs(dS_d).max())

@@ -231,3 +231,39 @@ def test_neighbour_view_rule_matches_reference():
     assert adjacent_views(1, 50, 4) == [0, 2, 3, 4]
     assert adjacent_views(35, 50, 4) == [33, 34, 36, 37]
     assert adjacent_views(50, 50, 4) == [46, 47, 48, 49]
+
+
+def test_private_accumulators_sum_what_the_shared_one_sums(oracle_mod):
+    """bench.py's cpu_baseline times the oracle's multi-threaded K1 twice: `omp atomic` adds into
+    ONE accumulator, and a private accumulator per thread merged at the end
+    (Oracle.set_private_accumulators).  Same lists, columns and messages; the accumulator is the
+    same sum in another order."""
+    from conftest import GOLDEN
+    from raynet_amd.common.scene import restrepo_cameras_scene
+    H, W = 36, 64
+    scene = restrepo_cameras_scene(os.path.join(GOLDEN, "restrepo_mock_scene_1"), (H, W),
+                                   scale=W / 1280.0)
+    rng = np.random.default_rng(5)
+    feats = (rng.standard_normal((2, H + 12, W + 12, 32)) * 0.25).astype(np.float32)
+    P = np.array([scene.get_image(v).camera.P for v in (0, 1)], np.float32)
+    cam = scene.get_image(0).camera
+    Pi, cc = cam.P_pinv.astype(np.float32), cam.center.ravel().astype(np.float32)
+    vg = oracle_mod.voxel_grid_centers(scene.bbox.ravel(), (32, 32, 32))
+    ridx = np.arange(H * W, dtype=np.int32)
+    res = {}
+    for tag, threads, private in (("one", 1, False), ("shared", 4, False), ("private", 4, True)):
+        o = oracle_mod.Oracle(M=96, D=16, N=2, F=32, H=H, W=W, padding=11, bbox=scene.bbox.ravel(),
+                              grid_shape=(32, 32, 32), threads=threads)
+        oracle_mod.Oracle.set_private_accumulators(private)
+        try:
+            out = o.prior(0.05)
+            msgs = np.zeros((H * W, 96), np.float32)
+            rvi, rvc, Sv = o.fused_bp(ridx, feats, P, Pi, cc, vg, o.prior(0.05), msgs, out)
+        finally:
+            oracle_mod.Oracle.set_private_accumulators(False)
+        res[tag] = (rvi, rvc, Sv, msgs, out)
+    for tag in ("shared", "private"):
+        for a, b in zip(res[tag][:4], res["one"][:4]):
+            assert np.array_equal(a, b)
+        assert np.abs(res[tag][4] - res["one"][4]).max() <= 1e-4
+    assert np.abs(res["one"][4] - res["one"][4][0, 0, 0]).max() > 1.0      # (messages did arrive)
