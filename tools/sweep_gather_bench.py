@@ -23,6 +23,10 @@ VARIANTS = {0: "ray order, 8 lanes per vector (the product's)", 1: "ray order, l
             2: "16x16 tile, bands of 16 planes, 16 waves", 3: "tile, bands of 8, 16 waves",
             4: "tile, bands of 32, 16 waves", 5: "tile, bands of 16, 8 waves",
             6: "tile, bands of 64, 16 waves (control: ray order inside a synchronised tile)",
+            20: "FOOTPRINT-STAGED tile: bands of 8, row segments by LDS-DMA, vector reads from LDS",
+            21: "footprint-staged tile, bands of 4",
+            22: "footprint-staged tile, bands of 16",
+            23: "footprint-staged tile, bands of 8, 8 waves",
             10: "ray order, all 32 loads of a chunk in flight, default cache policy",
             11: "... nt", 12: "... sc0", 13: "... sc1", 14: "... sc0 sc1", 15: "... sc0 sc1 nt"}
 
@@ -43,6 +47,7 @@ def main():
     ap.add_argument("--variants", default="0,1,2,3,4,5,6")
     ap.add_argument("--lds", type=int, default=131072, help="dynamic LDS of the tile kernels (occupancy cap)")
     ap.add_argument("--ray-lds", type=int, default=0, help="dynamic LDS of the ray-order kernel (occupancy cap)")
+    ap.add_argument("--stage", type=int, default=155000, help="LDS bytes the footprint-staged tile may fill")
     ap.add_argument("--chunk", type=int, default=512, help="workgroups side by side on one XCD (ray order)")
     ap.add_argument("--tile-chunk", type=int, default=8, help="tiles side by side on one XCD")
     ap.add_argument("--once", action="store_true", help="one launch per variant (for counter passes)")
@@ -80,6 +85,9 @@ def main():
     ptrs = (ctypes.c_void_p * N)(*[m.data_ptr() for m in maps])
     lib = ctypes.CDLL(build())
     lib.sgb_run.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
+    lib.sgb_set_lds_variant.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    stats = torch.zeros((4,), dtype=torch.int32, device="cuda")
+    lib.sgb_set_lds_variant(W + pad + 1, stats.data_ptr())
     out = torch.zeros((max(n * 64, ((n + 255) // 256) * 1024),), device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     n_live = int((live > 1).sum())
@@ -89,11 +97,12 @@ def main():
            "gathered_GB": round(gathered / 1e9, 3), "unique_GB": round(unique / 1e9, 4),
            "lds_bytes_tile_kernels": args.lds, "variants": {}}
     for v in [int(x) for x in args.variants.split(",")]:
-        chunk = args.chunk if v < 2 else args.tile_chunk
+        chunk = args.chunk if (v < 2 or 10 <= v < 20) else args.tile_chunk
+        lds_v = args.stage if v >= 20 else (args.lds if 2 <= v < 10 else args.ray_lds)
 
         def run():
             rc = lib.sgb_run(v, n, N, D, offs.data_ptr(), live.data_ptr(), ptrs, out.data_ptr(), chunk,
-                             args.lds if v >= 2 else args.ray_lds, stream)
+                             lds_v, stream)
             assert rc == 0, rc
         if args.once:
             run()
@@ -111,6 +120,21 @@ def main():
             best = min(best, a.elapsed_time(b))
         rep["variants"][str(v)] = {"what": VARIANTS[v], "ms": round(best, 3),
                                    "L1_side_TBps": round(gathered / best / 1e9, 2)}
+        if v >= 20:
+            stats.zero_()
+            run()
+            torch.cuda.synchronize()
+            st = stats.cpu().numpy().astype(np.int64)
+            rep["variants"][str(v)].update(
+                bands=int(st[0]), bands_gathering_from_global=int(st[1]), staged_pixels=int(st[2]) * 16,
+                staged_GB=round(int(st[2]) * 16 * 128 / 1e9, 3), stage_bytes=lds_v,
+                checksum=float(out[:((n + 255) // 256) * 1024].double().sum()))
+            # what the staged reads must add up to: every live ray's vectors, straight from the maps
+            expect = 0.0
+            for vv in range(1, N):
+                vs = maps[vv].reshape(-1, F).double().sum(1)
+                expect += float(vs[offs[live > 1][:, vv].reshape(-1).long()].sum())
+            rep["variants"][str(v)]["checksum_expected"] = expect
         print("variant %d  %-75s %8.3f ms   %6.2f TB/s of gathered vectors" % (v, VARIANTS[v], best,
                                                                                 gathered / best / 1e9), flush=True)
     if not args.once:
