@@ -367,6 +367,55 @@ __device__ __forceinline__ void planes_out(const Params &p, int r, const float s
     }
 }
 
+// ... and for the RPW rays of a wavefront of k_sweep_map_packed at once: lane l = plane l % DPAD of
+// ray l / DPAD (its row in `r`, its segment in s / e), the arg-max folded within the ray's lanes.
+// The comparisons are planes_out's (larger value, then smaller index): the same plane wins.
+template <int RPW>
+__device__ __forceinline__ void planes_out_packed(const Params &p, int r, const float s[3],
+                                                  const float e[3], const float *Sl, int lane,
+                                                  int nrays, const float *__restrict__ cc,
+                                                  float *S_planes, float *depth_from_planes,
+                                                  float *points) {
+    constexpr int DPAD = WAVE / RPW;
+    const int q = lane / DPAD, k = lane % DPAD;
+    const bool mine = k < p.D && q < nrays;
+    float best = -INFINITY;
+    int best_k = 0;
+    if (mine) {
+        const float v = Sl[q * p.D + k];
+        S_planes[(size_t)r * p.D + k] = v;
+        if (depth_from_planes) {
+            float pt[3];
+            plane_point(s, e, k, p.D, pt);
+            reinterpret_cast<float4 *>(points)[(size_t)r * p.D + k] = make_float4(pt[0], pt[1], pt[2], 1.0f);
+            if (v > best) {
+                best = v;
+                best_k = k;
+            }
+        }
+    }
+    if (!depth_from_planes) return;
+#pragma unroll
+    for (int o = DPAD / 2; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int ok = __shfl_xor(best_k, o);
+        if (ob > best || (ob == best && ok < best_k)) {
+            best = ob;
+            best_k = ok;
+        }
+    }
+    if (k == 0 && q < nrays) {
+        float pt[3];
+        plane_point(s, e, best_k, p.D, pt);
+        float sum = 0.0f;
+        for (int i = 0; i < 3; i++) {
+            const float d = pt[i] - cc[i];
+            sum += d * d;
+        }
+        depth_from_planes[r] = sqrtf(sum);
+    }
+}
+
 // MAPMODE 1 / 2 / 3's tail for one ray: planes -> voxels from the softmaxed column Sl, then the
 // normalised column (1), clip + renormalise (2), and BP iteration 0's messages (3)
 template <int MAPMODE, bool PACKED>
@@ -614,6 +663,10 @@ void k_sweep_map_packed(
     wave_sync();
     softmax_columns<RESIDENT, RPW>(p.D, lane, Sl);
     wave_sync();
+    if (MAPMODE == 0) {          // K7 / K9 / K10: no per-voxel tail, the rays stay side by side
+        planes_out_packed<RPW>(p, r, s, e, Sl, lane, nrays, cc, S_planes, depth_from_planes, points);
+        return;
+    }
     for (int q = 0; q < nrays; q++) {
         // ray q's row, segment and count from its first lane into SGPRs: the tail is k_sweep_map's
         const int rq = __builtin_amdgcn_readlane(r, q * DPAD);
@@ -622,10 +675,6 @@ void k_sweep_map_packed(
         for (int i = 0; i < 3; i++) {
             su[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s[i]), q * DPAD));
             eu[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e[i]), q * DPAD));
-        }
-        if (MAPMODE == 0) {
-            planes_out(p, rq, su, eu, Sl + q * p.D, lane, cc, S_planes, depth_from_planes, points);
-            continue;
         }
         const int cq = __builtin_amdgcn_readlane(count, q * DPAD);
         if (RESIDENT && cq <= 1) continue;

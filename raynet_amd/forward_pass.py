@@ -271,6 +271,7 @@ class _Messages(dict):
     def __init__(self):
         super(_Messages, self).__init__()
         self._tail = {}
+        self.width = None      # the caller's M when the rows are stored with a padded stride
 
     def put(self, r, msgs, counts):
         dict.__setitem__(self, r, msgs)
@@ -282,6 +283,8 @@ class _Messages(dict):
         if counts is not None and m.numel():
             live = torch.where(counts > 1, counts, torch.zeros_like(counts))
             m.masked_fill_(torch.arange(m.shape[1], device=m.device)[None, :] >= live[:, None], 0.0)
+        if self.width is not None and m.shape[1] != self.width:
+            return m[:, :self.width]      # [rows, M] as the reference has it (forward_pass.py:560-566)
         return m
 
 
@@ -352,6 +355,27 @@ class RayNetForwardPass(ForwardPass):
         self._acc_grid, self._acc_flat, self._acc_bias = value, None, 0.0
 
     # -- helpers -----------------------------------------------------------
+    def _rows_M(self):
+        """Row length of the resident buffers (see _row_stride; a stand-in back end keeps M)."""
+        return getattr(self, "_M_rows", None) or self._generation_params.max_number_of_marched_voxels
+
+    def _row_stride(self, M, grid_shape):
+        """Row length of the resident [rows][M] buffers.  They are this driver's own (the reference
+        keeps its messages in a memmap of the same shape, forward_pass.py:560-566, and everything
+        else in per-batch arrays), so a row may be LONGER than M as long as no ray's list can be:
+        a DDA moves monotonically along every axis, a list holds at most gx + gy + gz - 2 voxels, and
+        with M at or above that the `count > M` truncation never fires -- the lists, columns,
+        messages and maps are what they are with rows of exactly M.  The kernels take whole
+        16-byte / 16-step pieces of a row when its length is a multiple of 16 (the traversal's
+        flush, the scatters' loads): the reference's own default M = 650 (scripts/arguments.py:221)
+        becomes 656 here (k_traverse 2.9 -> 1.5 ms per step at its CLI defaults).  The literal
+        K1 / K2 schedule and truncating shapes keep M."""
+        if self.schedule != "resident" or self.reference_quirks or M % 16 == 0:
+            return int(M)
+        if int(M) < int(np.sum(grid_shape)) - 2:
+            return int(M)
+        return (int(M) + 15) // 16 * 16
+
     def _context(self, scene, F):
         if self._ctx is None:
             gp = self._generation_params
@@ -362,8 +386,10 @@ class RayNetForwardPass(ForwardPass):
                     gp.max_number_of_marched_voxels, gp.depth_planes, gp.neighbors + 1, F, H, W,
                     gp.padding, scene.bbox.ravel(), grid_shape)
             else:
+                self._M_rows = self._row_stride(gp.max_number_of_marched_voxels, grid_shape)
+                self.messages.width = gp.max_number_of_marched_voxels
                 self._fp, self._de = perform_raynet_fp(
-                    gp.max_number_of_marched_voxels, gp.depth_planes, gp.neighbors + 1, F, H, W,
+                    self._M_rows, gp.depth_planes, gp.neighbors + 1, F, H, W,
                     gp.padding, scene.bbox.ravel(), grid_shape, self._sampling_scheme)
                 self._ctx = self._fp.context
             self._vg = self._ctx.dev(np.ascontiguousarray(
@@ -514,7 +540,7 @@ class RayNetForwardPass(ForwardPass):
         iterations); the voxel lists and columns of as many images as fit -- the rest are
         recomputed group by group in every sweep, like the reference recomputes everything."""
         gp, opt, dev = self._generation_params, self.options, ctx.device
-        M, V, npad = gp.max_number_of_marched_voxels, len(refs), plan["npad"]
+        M, V, npad = self._rows_M(), len(refs), plan["npad"]
         G = ctx.acc_size()
         per_image = npad * M * 4
         budget = float(opt.resident_gb) * 2 ** 30
@@ -556,7 +582,7 @@ class RayNetForwardPass(ForwardPass):
 
     def _build_plan(self, scene, refs, bank, ctx, dist, rank, world):
         gp, opt = self._generation_params, self.options
-        M, N = gp.max_number_of_marched_voxels, gp.neighbors + 1
+        M, N = self._rows_M(), gp.neighbors + 1
         H, W = scene.image_shape
         dev = ctx.device
         V = len(refs)

@@ -6,7 +6,7 @@ cuda_implementations/raynet_fp.py:288; everything else is baked into the PyCUDA 
 scatter (and `deterministic`, which removes even that).  `RayNetForwardPass(..., options=...)`
 takes one; `bench.py` echoes it in its JSON line so that an A/B run can be reproduced from the
 line alone.  Environment variables are overrides only and are read HERE and nowhere else in the
-package (`PathOptions.from_env`); the C library reads its own five in `rn_create`
+package (`PathOptions.from_env`); the C library reads its own six in `rn_create`
 (include/raynet_hip.h, `rn_options`) for callers that bind the C ABI directly -- the Python
 mirror always sets them explicitly.
 """

@@ -70,20 +70,26 @@ def _depth_close(a, b, dist=None, W=None, H=None):
     return bad.mean()
 
 
-@pytest.mark.parametrize("quirks", [False, True])
-def test_resident_vs_reference_schedule_vs_oracle(torch, oracle_mod, quirks):
+@pytest.mark.parametrize("quirks,M", [(False, 96), (True, 96), (False, 100)])
+def test_resident_vs_reference_schedule_vs_oracle(torch, oracle_mod, quirks, M):
+    """M = 100: not a multiple of 16 and no list can reach it (32 + 32 + 32 - 2 = 94): the resident
+    buffers' rows are 112 long (RayNetForwardPass._row_stride), the results those of M = 100 (the
+    literal K1 / K2 schedule and the oracle run with rows of exactly 100)."""
     from raynet_amd.forward_pass import get_forward_pass_factory
     from raynet_amd.synthetic import make_synthetic_scene
-    H, W, D, M, grid = 24, 32, 16, 96, (32, 32, 32)
+    H, W, D, grid = 24, 32, 16, (32, 32, 32)
     scene, bank = make_synthetic_scene(H=H, W=W, n_views=5, focal=1.5 * H)
     gp = _gp(D, M, grid)
     refs = (0, 3, 1)
     cls = get_forward_pass_factory("raynet")
     fa = cls(bank, gp, "sample_in_bbox", (H, W), 300, reference_quirks=quirks)
     da = list(fa.forward_pass(scene, refs))
+    assert fa._rows_M() == (112 if M == 100 else 96)
+    assert tuple(fa.messages[0].shape) == (H * W, M)
     fb = cls(bank, gp, "sample_in_bbox", (H, W), 300, schedule="reference",
              reference_quirks=quirks)
     db = list(fb.forward_pass(scene, refs))
+    assert fb._rows_M() == M
     assert len(da) == len(db) == 3 and da[0].shape == (H, W) and da[0].dtype == np.float32
     # the comparator is the oracle's robust message form (pinned to the reference's NumPy path,
     # tests/test_saturated_golden.py): on this planted scene messages reach |m| = 12, where the

@@ -87,8 +87,16 @@ def test_path_options_defaults_env_overrides_and_key():
     """One object for every knob; the environment only overrides defaults, parsed in one place."""
     from raynet_amd.hip_implementations.options import PathOptions, shard_alpha_for
     d = PathOptions()
-    assert d.ray_tile == (16, 16) and d.overlap == 2 and not d.deterministic and d.plan_path
-    assert d.context_options() == (-1, 0, 0, 2, 0)
+    assert d.ray_tile == (16, 16) and d.overlap == 2 and d.plan_path
+    # fixed-point sums: by the rank count unless said otherwise (SURVEY.md 8e: a sharded run's
+    # result is the one-rank result, bit for bit, by default)
+    assert d.deterministic is None and not d.fixed_point(1) and d.fixed_point(2) and d.fixed_point(8)
+    assert PathOptions(deterministic=False).fixed_point(8) is False
+    assert PathOptions(deterministic=True).fixed_point(1) is True
+    assert PathOptions.from_env({"RAYNET_DETERMINISTIC": "auto"}).deterministic is None
+    assert PathOptions.from_env({"RAYNET_DETERMINISTIC": "0"}).deterministic is False
+    assert d.context_options() == (-1, 0, 0, 2, 0, 0)
+    assert PathOptions.from_env({"RAYNET_HIP_SWEEP_RAYS_PER_WAVE": "1"}).context_options()[5] == 1
     env = {"RAYNET_RAY_TILE": "0", "RAYNET_DETERMINISTIC": "1", "RAYNET_HIP_OVERLAP": "1",
            "RAYNET_SHARD_ALPHA": "0.45", "RAYNET_RESIDENT_GB": "1.5", "RAYNET_SLAB_BOXES": "0",
            "RAYNET_HIP_BOX_LEVEL": "1", "RAYNET_EXCHANGE": "reduce_scatter", "UNRELATED": "x"}

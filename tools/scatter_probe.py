@@ -63,7 +63,13 @@ def main():
         visits = float(sum(float(fp.voxel_count[r].sum().item()) for r in fp.voxel_count))
         rays = float(sum(int(fp.voxel_count[r].numel()) for r in fp.voxel_count))
         st = ctx.scatter_state()
-        run = {"box_level": lv, "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(fam.items())},
+        import time
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        ms_step = (time.perf_counter() - t0) / 5 * 1e3
+        run = {"box_level": lv, "ms_per_step": round(ms_step, 3), "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(fam.items())},
                "scatter_state": st,
                "scatter_algorithmic_GBps": round(3 * (8 * visits + 4 * rays) / (fam["scatter"] * 1e-3) / 1e9, 1),
                "mean_voxels_per_ray": round(visits / rays, 1)}
