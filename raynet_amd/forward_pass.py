@@ -206,14 +206,28 @@ class MultiViewCNNForwardPass(ForwardPass):
                     self._sampling_scheme)
             ctx = self._fp.context
             P, P_inv, center = (ctx.dev(a) for a in self._camera_arrays(images))
-            ridx = ctx.dev(ray_idxs.astype(np.int32))
-            s = torch.zeros((min(B, len(ridx)), gp.depth_planes), dtype=torch.float32,
-                            device=ctx.device)
-            pts = torch.zeros((len(s), gp.depth_planes, 4), dtype=torch.float32,
-                              device=ctx.device)
+            # The reference uploads the ray list and allocates zero-filled S / points per image
+            # (forward_pass.py:283-300).  K10 writes every entry of the rows it is handed, so the
+            # scratch buffers live with the driver (no 66 MB memset per image at 130,000 rays x 32
+            # planes), and the full ray list of an unfiltered image is uploaded once.
+            nb = max(1, min(B, len(ray_idxs)) if B else len(ray_idxs))
+            buf = getattr(self, "_k10_buffers", None)
+            if buf is None or buf["key"] != (nb, gp.depth_planes, H * W, str(ctx.device)):
+                buf = dict(key=(nb, gp.depth_planes, H * W, str(ctx.device)),
+                           s=torch.empty((nb, gp.depth_planes), dtype=torch.float32, device=ctx.device),
+                           pts=torch.empty((nb, gp.depth_planes, 4), dtype=torch.float32, device=ctx.device),
+                           all_rays=None)
+                self._k10_buffers = buf
+            if self._filter_out_rays:
+                ridx = ctx.dev(ray_idxs.astype(np.int32))
+            else:
+                if buf["all_rays"] is None:
+                    buf["all_rays"] = ctx.dev(ray_idxs.astype(np.int32))
+                ridx = buf["all_rays"]
+            s, pts = buf["s"], buf["pts"]
             depth_map = torch.zeros((H * W,), dtype=torch.float32, device=ctx.device)
-            for i in range(0, len(ridx), B):
-                self._fp(ridx[i:i + B], features, P, P_inv, center, s, pts, depth_map[i:i + B])
+            for i in range(0, len(ridx), nb):
+                self._fp(ridx[i:i + nb], features, P, P_inv, center, s, pts, depth_map[i:i + nb])
             ref_idx += skip
             yield depth_map.cpu().numpy().reshape(W, H).T
 

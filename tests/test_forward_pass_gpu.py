@@ -661,8 +661,17 @@ def test_unaligned_slices_are_accepted(torch):
             assert np.isfinite(out[M, batch]).all()
         assert np.array_equal(out[M, 0], out[M, 50]) and np.array_equal(out[M, 0], out[M, 300])
     assert (np.abs(out[96, 0] - out[98, 0]) > 1e-4).mean() < 0.01      # M only pads the rows
+    assert fp._rows_M() == 112      # (no list can reach 98 in a 32^3 grid: rows of 112, _row_stride)
+    # ... and rows of exactly 98 (a grid whose lists CAN reach M keeps it: 36 + 36 + 36 - 2 = 106)
+    gp = _gp(16, 98, (36, 36, 36), neighbors=2)
+    scene, _ = make_synthetic_scene(H=H, W=W, n_views=3, focal=1.5 * H)     # (a scene caches its grid)
+    for batch in (0, 50):
+        fp = cls(bank, gp, "sample_in_bbox", (H, W), batch,
+                 options=PathOptions(deterministic=True, ray_tile=None))
+        out[36, batch] = np.stack(list(fp.forward_pass(scene, (0, 3, 1))))
+    assert fp._rows_M() == 98 and np.isfinite(out[36, 0]).all()
+    assert np.array_equal(out[36, 0], out[36, 50])
     # the entry point itself on slices that start at odd elements
-    from raynet_amd.hip_implementations import get_context
     ctx = fp._ctx
     n = 37
     ridx = torch.arange(1, n + 1, dtype=torch.int32, device="cuda")[1:]
