@@ -291,6 +291,10 @@ class _Messages(dict):
         dict.__setitem__(self, r, msgs)
         self._tail[r] = counts
 
+    def clear(self):
+        dict.clear(self)
+        self._tail.clear()
+
     def __getitem__(self, r):
         m = dict.__getitem__(self, r)
         counts = self._tail.pop(r, None)
@@ -645,7 +649,17 @@ class RayNetForwardPass(ForwardPass):
         if self._side_stream is not None:           # nobody reads the outgoing buffers any more
             torch.cuda.current_stream(dev).wait_stream(self._side_stream)
             torch.cuda.current_stream(dev).wait_stream(self._copy_stream)
-        self._plan = plan = None                     # release the old buffers first
+        # release the old buffers first -- ALL references this driver holds to them: the plan, the
+        # record of the last call (it holds the plan), and the last pass's outputs that are views
+        # of the plan's buffers (messages, counts, the accumulator).  A new scene invalidates them
+        # exactly as the next pass over the same scene would have rewritten them; whatever a
+        # caller still holds stays alive through the caller's own reference.  The allocator then
+        # hands the very blocks to the new plan: no second 7 GB set, no fresh allocation.
+        self._plan = plan = None
+        self._quick = None
+        self.messages.clear()
+        self.voxel_count.clear()
+        self._acc_flat = self._acc_grid = None
         if hasattr(ctx, "bind_slab_boxes"):
             ctx.bind_slab_boxes(None)                # (the binding holds the old list buffer)
         if getattr(ctx, "_scatter_items", None) is not None:
@@ -989,6 +1003,7 @@ class RayNetForwardPass(ForwardPass):
                 plan, ctx = q["plan"], self._ctx
                 ctx.set_options(self.options)
                 dev = ctx.device
+        q = None        # (this frame must not keep the old plan alive while a new one is allocated)
         self._acc_flat = self._acc_grid = None
         self._acc_bias = 0.0
         if plan is None:

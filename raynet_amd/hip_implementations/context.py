@@ -571,14 +571,16 @@ class HipContext(object):
                 lo, hi = int(ray_idxs.min()), int(ray_idxs.max())
                 assert 0 <= lo and hi < depth_image.shape[1], (lo, hi, tuple(depth_image.shape))
             pl.depth_image, pl.depth_image_stride = depth_image.data_ptr(), int(depth_image.shape[1])
+        # (the tensors the struct points into live as long as it does.  No `byref(pl)` is kept ON
+        # pl: that is a reference cycle through a ctypes object the collector does not track --
+        # every plan ever built, with its 7 GB of buffers, stayed allocated: round 6)
         pl._keepalive = (ray_idxs, feature_table, cameras, vox, rvc, Sr, msgs, acc0, acc1, depth,
                          acc_fixed, order, seg, depth_image)
-        pl._ref = ctypes.byref(pl)
         return pl
 
     def scene_run(self, plan, phases, iteration=0, image=-1):
         """rn_scene_run: the phases (a mask of _lib.RN_RUN_*) of one pass, one C call."""
-        self._check(self.lib.rn_scene_run(self._h, plan._ref, int(phases), int(iteration),
+        self._check(self.lib.rn_scene_run(self._h, ctypes.byref(plan), int(phases), int(iteration),
                                           int(image), _stream()))
 
     def count_voxels(self, ray_idxs, cameras):
