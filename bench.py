@@ -161,6 +161,8 @@ def live_pmc(config, family, budget_s=180.0):
                                                   "-d", d, "-o", "p", "--", sys.executable,
                                                   os.path.abspath(__file__), "--steps", "1",
                                                   "--warmup", "1", "--no-cpu-baseline", "--no-config4",
+                                                  "--no-reference-shapes",     # (their sweeps would
+                                                  # be averaged into the counters per launch)
                                                   "--pmc", "off", "--config", config]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL, timeout=min(left, 60.0))

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$R/gpurun_out/pmc}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --pmc off ${BENCH_ARGS:-}"
+CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --pmc off --no-config4 --no-reference-shapes ${BENCH_ARGS:-}"
 i=0
 for SET in \
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
