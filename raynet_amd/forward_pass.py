@@ -258,19 +258,29 @@ class MultiViewCNNVoxelSpaceForwardPass(ForwardPass):
                 vg = ctx.dev(np.ascontiguousarray(
                     scene.voxel_grid(gp.grid_shape).transpose(1, 2, 3, 0)))
             P, P_inv, center = (ctx.dev(a) for a in self._camera_arrays(images))
-            ridx = ctx.dev(ray_idxs.astype(np.int32))
-            nb = min(B, len(ridx))
-            s = torch.zeros((nb, M), dtype=torch.float32, device=ctx.device)
-            rvi = torch.zeros((nb, M, 3), dtype=torch.int32, device=ctx.device)
-            rvc = torch.zeros((nb,), dtype=torch.int32, device=ctx.device)
+            # (as MultiViewCNNForwardPass: K12 writes every count, and reads a list and a column only
+            # up to the ray's count -- the scratch rows need no 1 GB memset per batch of 130,000
+            # rays x 650 voxels, and live with the driver)
+            nb = max(1, min(B, len(ray_idxs)) if B else len(ray_idxs))
+            buf = getattr(self, "_k12_buffers", None)
+            if buf is None or buf["key"] != (nb, M, H * W, str(ctx.device)):
+                buf = dict(key=(nb, M, H * W, str(ctx.device)),
+                           s=torch.zeros((nb, M), dtype=torch.float32, device=ctx.device),
+                           rvi=torch.zeros((nb, M, 3), dtype=torch.int32, device=ctx.device),
+                           rvc=torch.zeros((nb,), dtype=torch.int32, device=ctx.device), all_rays=None)
+                self._k12_buffers = buf
+            if self._filter_out_rays:
+                ridx = ctx.dev(ray_idxs.astype(np.int32))
+            else:
+                if buf["all_rays"] is None:
+                    buf["all_rays"] = ctx.dev(ray_idxs.astype(np.int32))
+                ridx = buf["all_rays"]
+            s, rvi, rvc = buf["s"], buf["rvi"], buf["rvc"]
             depth_map = torch.zeros((H * W,), dtype=torch.float32, device=ctx.device)
-            for i in range(0, len(ridx), B):
-                s.zero_()
-                rvi.zero_()
-                rvc.zero_()
-                k = len(ridx[i:i + B])
-                self._fp(ridx[i:i + B], features, P, P_inv, center, vg, rvi[:k], rvc[:k], s[:k],
-                         depth_map[i:i + B])
+            for i in range(0, len(ridx), nb):
+                k = len(ridx[i:i + nb])
+                self._fp(ridx[i:i + nb], features, P, P_inv, center, vg, rvi[:k], rvc[:k], s[:k],
+                         depth_map[i:i + nb])
             ref_idx += skip
             yield depth_map.cpu().numpy().reshape(W, H).T
 
