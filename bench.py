@@ -475,7 +475,18 @@ def main():
     extra_warmup = 0
     capturable = fp.options.capture == "on" or (world > 1 and backend == "nccl" and
                                                   fp.options.capture == "auto")
-    while capturable and not fp.captured and extra_warmup < 8:
+    # (... the same number on EVERY rank: a rank whose scatter stepped to another tile shape settles
+    # -- and captures -- a pass or two later than the others, and a rank that warms up longer than its
+    # peers would leave them waiting in the collectives of a step they never run.  The ranks agree
+    # after every pass: untimed, one 4-byte all-reduce.)
+    while capturable and extra_warmup < 8:
+        done = bool(fp.captured)
+        if world > 1:
+            flag = torch.tensor([1 if done else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(int(flag.item()))
+        if done:
+            break
         step()
         extra_warmup += 1
     # Which family dominates: by its SHARE of the timeline, not by the sum of its launches'
