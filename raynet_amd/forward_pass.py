@@ -321,18 +321,13 @@ class RayNetForwardPass(ForwardPass):
 
     def __init__(self, model, generation_params, sampling_scheme, image_shape, rays_batch,
                  filter_out_rays=False, bp_iterations=3, schedule="resident",
-                 reference_quirks=False, backend_factory=None, deterministic=None, options=None):
+                 reference_quirks=False, deterministic=None, options=None):
         super(RayNetForwardPass, self).__init__(model, generation_params, sampling_scheme,
                                                 image_shape, rays_batch, filter_out_rays)
         assert schedule in ("resident", "reference")
         self.bp_iterations = bp_iterations      # the reference hard-codes 3 (forward_pass.py:590)
         self.schedule = schedule
         self.reference_quirks = reference_quirks
-        # backend_factory(M, D, N, F, H, W, padding, bbox, grid_shape) -> object with the
-        # resident-scene methods of HipContext.  None = the HIP library.  (The
-        # world_size-2 gloo test injects a host stand-in to exercise the sharding and
-        # all-reduce logic without a GPU.)
-        self._backend_factory = backend_factory
         # every schedule / A-B knob lives in ONE PathOptions (hip_implementations/options.py);
         # the environment only overrides its defaults, read there.  `deterministic=True`
         # (messages summed as 64-bit fixed-point integers in the scatter, the accumulator and the
@@ -384,7 +379,7 @@ class RayNetForwardPass(ForwardPass):
 
     # -- helpers -----------------------------------------------------------
     def _rows_M(self):
-        """Row length of the resident buffers (see _row_stride; a stand-in back end keeps M)."""
+        """Row length of the resident buffers (see _row_stride)."""
         return getattr(self, "_M_rows", None) or self._generation_params.max_number_of_marched_voxels
 
     def _row_stride(self, M, grid_shape):
@@ -409,17 +404,12 @@ class RayNetForwardPass(ForwardPass):
             gp = self._generation_params
             H, W = scene.image_shape
             grid_shape = np.array(scene.voxel_grid(gp.grid_shape).shape[1:])
-            if self._backend_factory is not None:
-                self._ctx = self._backend_factory(
-                    gp.max_number_of_marched_voxels, gp.depth_planes, gp.neighbors + 1, F, H, W,
-                    gp.padding, scene.bbox.ravel(), grid_shape)
-            else:
-                self._M_rows = self._row_stride(gp.max_number_of_marched_voxels, grid_shape)
-                self.messages.width = gp.max_number_of_marched_voxels
-                self._fp, self._de = perform_raynet_fp(
-                    self._M_rows, gp.depth_planes, gp.neighbors + 1, F, H, W,
-                    gp.padding, scene.bbox.ravel(), grid_shape, self._sampling_scheme)
-                self._ctx = self._fp.context
+            self._M_rows = self._row_stride(gp.max_number_of_marched_voxels, grid_shape)
+            self.messages.width = gp.max_number_of_marched_voxels
+            self._fp, self._de = perform_raynet_fp(
+                self._M_rows, gp.depth_planes, gp.neighbors + 1, F, H, W,
+                gp.padding, scene.bbox.ravel(), grid_shape, self._sampling_scheme)
+            self._ctx = self._fp.context
             self._vg = self._ctx.dev(np.ascontiguousarray(
                 scene.voxel_grid(gp.grid_shape).transpose(1, 2, 3, 0)))   # forward_pass.py:573-575
             self._ctx.set_voxel_grid(self._vg)

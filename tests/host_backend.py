@@ -1,9 +1,9 @@
 """A HOST stand-in for HipContext's resident-scene methods, built on the oracle.
 
 TEST INFRASTRUCTURE.  It exists so the world_size-2 gloo test can drive the real
-RayNetForwardPass sharding / all-reduce / prior-once logic on CPU tensors; it is
-injected through the driver's `backend_factory` hook and is never importable from
-the product package."""
+RayNetForwardPass sharding / all-reduce / prior-once logic on CPU tensors; the test's
+rank processes put it where the driver looks for its context (they replace
+raynet_amd.forward_pass.perform_raynet_fp); it is never importable from the product package."""
 import numpy as np
 import torch
 

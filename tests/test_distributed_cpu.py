@@ -1,7 +1,8 @@
 """world_size-2 gloo run of the real RayNetForwardPass driver on CPU tensors.
 
-The HIP kernels cannot run here, so the driver's backend hook receives a host
-stand-in built on the oracle (tests/host_backend.py); what is under test is the
+The HIP kernels cannot run here, so each rank's process replaces the factory the driver takes
+its context from (perform_raynet_fp) with a host stand-in built on the oracle
+(tests/host_backend.py); what is under test is the
 multi-GPU logic of forward_pass.py: contiguous ray sharding, zero-initialised local
 accumulators, ONE all-reduce per BP iteration with the prior added once after it
 (SURVEY.md 8e), and the merge of the per-rank depth slices."""
@@ -41,9 +42,19 @@ def _run(rank, world, port, out_dir, filtered=False):
         masks = [(rng.random((H, W)) > 0.35).astype(np.float32) for _ in range(VIEWS)]
         type(scene).get_depth_map = lambda self, i: masks[i]
     from raynet_amd.forward_pass import map_owner
+    # The driver takes its context from perform_raynet_fp's closures (as the reference's takes its
+    # kernels from there, forward_pass.py:579-590).  This process replaces THAT with a stand-in
+    # whose context is the host back end: the product class has no injection hook.
+    import raynet_amd.forward_pass as driver_module
+
+    def perform_raynet_fp_on_the_host(M_, D_, N_, F_, H_, W_, padding, bbox, grid_shape, scheme):
+        def not_here(*a, **k):
+            raise NotImplementedError("K1 / K2 closures: the resident schedule does not call them")
+        not_here.context = OracleBackend(M_, D_, N_, F_, H_, W_, padding, bbox, grid_shape)
+        return not_here, not_here
+    driver_module.perform_raynet_fp = perform_raynet_fp_on_the_host
     fp = get_forward_pass_factory("raynet")(bank, gp, "sample_in_bbox", (H, W), 50,
-                                            filter_out_rays=filtered,
-                                            backend_factory=OracleBackend)
+                                            filter_out_rays=filtered)
     depths = list(fp.forward_pass(scene, (0, VIEWS, 1)))
     # with a process group image k's map is handed out by ONE rank (map_owner; the reference
     # needs it once: forward_pass.py:739-744); the others yield None for it
