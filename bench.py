@@ -170,12 +170,15 @@ def live_pmc(config, family, budget_s=180.0):
                 if counters[0].startswith("TCC"):
                     continue
                 return None
-            tot, n = {}, {}
+            tot, n, everything = {}, {}, {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
+                        c = row["Counter_Name"]
+                        # (every kernel of the child's passes, the library's and torch's few alike:
+                        # the whole path's VALU time per pass, see `path_valu` below)
+                        everything[c] = everything.get(c, 0.0) + float(row["Counter_Value"])
                         if kernel in row.get("Kernel_Name", ""):
-                            c = row["Counter_Name"]
                             tot[c] = tot.get(c, 0.0) + float(row["Counter_Value"])
                             n[c] = n.get(c, 0) + 1
             for c in counters:
@@ -185,6 +188,9 @@ def live_pmc(config, family, budget_s=180.0):
                     continue            # (the newer, optional counters)
                 out[c] = tot[c] / n[c]
                 out["launches"] = n[c]
+                if c.startswith("SQ_") and family == "sweep_map":
+                    # one launch of the plane sweep per pass: all kernels' total per PASS
+                    out["path_" + c] = everything[c] / n[c]
         except Exception:
             return None
         finally:
@@ -513,6 +519,7 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    fence()         # (barrier + synchronize on both sides of the K timed steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -593,7 +600,7 @@ def main():
 
     fam = account(launches_all)             # the breakdown steps: every family
     timed = account(launches)               # the timed region: the dominant family (or all)
-    roofline = None
+    roofline = live = None
     if dominant and dominant in timed:
         d = timed[dominant]
         achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
@@ -889,6 +896,17 @@ def main():
     path_roofline = dict(bytes_per_ray=round(path_bytes / rays_per_step, 1),
                          achieved=round(path_gbps, 1), peak=HBM_PEAK_GBS * world, unit="GB/s",
                          frac=round(path_gbps / (HBM_PEAK_GBS * world), 4))
+    if live is not None and live.get("path_SQ_ACTIVE_INST_VALU"):
+        # The bound every kernel of this path is nearest to is VALU issue, not HBM: the cycles the
+        # chip's SIMDs were busy executing ALL kernels' VALU instructions of one pass (the counter
+        # pass's SQ_ACTIVE_INST_VALU, quad-cycles, summed over every kernel) against the SIMD
+        # cycles a step has
+        busy_ms = 4.0 * live["path_SQ_ACTIVE_INST_VALU"] / (N_SIMDS * VALU_CLOCK_HZ) * 1e3
+        path_roofline["valu"] = dict(
+            insts_per_step=live.get("path_SQ_INSTS_VALU"), busy_ms_per_step=round(busy_ms, 3),
+            frac_of_step=round(busy_ms / (elapsed / args.steps * 1e3), 4),
+            what="4 x SQ_ACTIVE_INST_VALU of every kernel of a pass / (%d SIMDs x %.1f GHz): the share "
+                 "of a step the VALUs are busy" % (N_SIMDS, VALU_CLOCK_HZ / 1e9))
     if rank == 0:
         result = {
             "metric": "rays/sec (whole node) at %d views x %d depths x %d^3 voxels" % (

@@ -42,7 +42,7 @@ constexpr int NXCD = 8;
 // much slower.)
 #define RN_XCD_CHUNK_SWEEP (2048 * 64 / 256)      /* workgroups: 2048 rays */
 #define RN_XCD_CHUNK_BP 256
-#define RN_XCD_CHUNK_DEPTH 0
+#define RN_XCD_CHUNK_DEPTH 1024    /* (contiguous eighths until round 6: config 4's k_depth 2.50 -> 2.32 ms per step with chunks of 1024 workgroups, config 2 within noise -- profiles/r06_l_variants_probe.txt) */
 #define RN_XCD_CHUNK_SCATTER 8
 template <int CHUNK = 0>
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
