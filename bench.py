@@ -519,13 +519,23 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    # The W untimed warm-up steps go HERE, back to back with the timed ones: the collection above (and
+    # the host work before it) leaves the GPU idle for tens of milliseconds, and the first passes
+    # after an idle spell run 5 - 15 % slower (step_ms.each of a run without them: 7.6, 7.0, 6.7, 6.6
+    # ... 6.4 ms -- the clocks come back over ~10 passes).  The passes further up (first-pass
+    # figures, the plan's settling, the breakdown) are untimed as well; these are the contract's W.
+    for _ in range(max(0, args.warmup)):
+        step()
     fence()         # (barrier + synchronize on both sides of the K timed steps)
     t0 = time.perf_counter()
+    step_ends = []
     for _ in range(args.steps):
         step()
+        step_ends.append(time.perf_counter())     # (a pass returns when its last map is on the host)
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    step_ms = [round((b - a) * 1e3, 3) for a, b in zip([t0] + step_ends[:-1], step_ends)]
     launches = [l for l in launches_all if only is None or l[0] in only] if graph_mode \
         else ctx.prof_end()
     ranks_report = None
@@ -953,6 +963,9 @@ def main():
             # + 20 c, B_de = 4NF HfWf/HW + 8 c + 4 (features once per sweep, per traversed voxel:
             # gather 4 + msg 4 + 4 + atomic RMW 8), over the step's wall time
             "path_roofline": path_roofline,
+            "step_ms": dict(each=step_ms[:32], min=min(step_ms), median=sorted(step_ms)[len(step_ms) // 2],
+                            what="this rank's wall time of every timed step (ms_per_step is their mean "
+                                 "incl. the closing barrier, MAX over ranks)"),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "other_configs": other_configs,
