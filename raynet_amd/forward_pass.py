@@ -354,6 +354,7 @@ class RayNetForwardPass(ForwardPass):
         self.messages = _Messages()   # per image: [rows, M] messages of this rank's rays
         self.voxel_count = {}
         self.ray_index = {}      # per image: ray index (pixel x*H + y) of every row
+        self._ray_lists = {}     # (shape, patch, direction, device) -> the scene-wide ray list (_plan_lists)
 
     # the options tests and tools flip on an existing object
     ray_tile = property(lambda self: self.options.ray_tile,
@@ -473,9 +474,18 @@ class RayNetForwardPass(ForwardPass):
                     rays = tile_order(rays, H, W, *opt.ray_tile, along_rows=along_rows)
             else:       # all H*W rays (forward_pass.py:166-168): built on the device, once
                 if shared is None:
-                    shared = torch.arange(H * W, dtype=torch.int32, device=dev)
-                    if patch_rows:
-                        shared = tile_order(shared, H, W, *opt.ray_tile, along_rows=along_rows)
+                    # (the list depends on the image shape, the patch and the direction only -- not on
+                    # the cameras: a caller looping over scenes, one pass each as the reference's
+                    # script does, gets it back instead of a sort per scene; read-only from here on)
+                    lkey = (H, W, opt.ray_tile, along_rows, str(dev))
+                    shared = self._ray_lists.get(lkey)
+                    if shared is None:
+                        shared = torch.arange(H * W, dtype=torch.int32, device=dev)
+                        if patch_rows:
+                            shared = tile_order(shared, H, W, *opt.ray_tile, along_rows=along_rows)
+                        if len(self._ray_lists) >= 4:
+                            self._ray_lists.clear()
+                        self._ray_lists[lkey] = shared
                 rays = shared
             lists[r] = rays
         self._along_rows = along_rows
@@ -564,9 +574,14 @@ class RayNetForwardPass(ForwardPass):
         budget = float(opt.resident_gb) * 2 ** 30
         if budget <= 0 and dev.type == "cuda":
             free, _ = torch.cuda.mem_get_info(dev)
-            # what the caching allocator holds but nobody uses is ours to take as well, and so
-            # are the outgoing plan's buffers (released below, before anything is allocated)
-            free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev) + old_bytes
+            # (everything resident: what this plan takes at most.  When the driver's own free memory
+            # holds it twice over there is nothing to decide, and the allocator's statistics --
+            # 0.3 ms of host time per new scene -- are not asked for)
+            if (V * per_image + 4 * G * 8 + V * npad * 48 + 2 * V * per_image) * 2 > free + old_bytes:
+                # what the caching allocator holds but nobody uses is ours to take as well, and so
+                # are the outgoing plan's buffers (released below, before anything is allocated)
+                free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            free += old_bytes
             budget = 0.9 * free
         fixed = V * per_image + 4 * G * 8 + V * npad * 48
         if budget > 0 and fixed + 2 * per_image > budget:
