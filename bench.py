@@ -346,8 +346,8 @@ def reference_shapes(torch, steps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="config2", choices=sorted(CONFIGS))
     ap.add_argument("--schedule", default="resident", choices=["resident", "reference"])
     ap.add_argument("--rays-batch", type=int, default=0, help="0 = one launch per image shard")
