@@ -247,3 +247,44 @@ def test_leases_taken_and_dropped_from_several_threads():
     del keep
     gc.collect()
     assert not st["live"]
+
+
+def test_the_committed_bench_line_keeps_the_drivers_contract():
+    """The round's last bench line (profiles/, produced by `python bench.py` on an MI355X) carries what the
+    driver's contract asks of the ONE JSON line -- metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload -- plus the two
+    objects of this tier, `roofline` and `cpu_baseline`, and its numbers agree with each other."""
+    import glob
+    import json
+    import os
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = sorted(glob.glob(os.path.join(REPO, "profiles", "r06_r_bench.json")))
+    assert lines, "no committed bench line"
+    d = json.loads([l for l in open(lines[-1]) if l.startswith("{")][-1])
+    for k, t in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int),
+                 ("warmup", int), ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str),
+                 ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)]:
+        assert isinstance(d[k], t), (k, type(d[k]))
+    assert d["vs_baseline"] is None                      # BASELINE.md publishes no number for this metric
+    assert d["metric"].startswith("rays/sec") and d["unit"] == "rays/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = rays of a step / time of a step
+    assert d["value"] == pytest.approx(d["config"]["rays_per_step"] / (d["ms_per_step"] * 1e-3), rel=1e-3)
+    # every timed step's wall time is in the line; their mean is the step time (one rank: no barrier wait)
+    each = d["step_ms"]["each"]
+    assert len(each) == min(d["steps"], 32) and sum(each) / len(each) == pytest.approx(d["ms_per_step"], rel=0.02)
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "valu", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-3) and 0 < r["frac"] < 1
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9,
+                                          rel=1e-3)
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.5
+    # the dominant kernel's launches fit into the steps they belong to
+    assert r["avg_launch_ms"] * r["launches"] <= d["ms_per_step"] * d["steps"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["unit"] == "rays/s" and c["cores"] >= 1 and c["value"] > 0
+    assert isinstance(c["sample"], str) and c["sample"]
+    assert d["value"] > 100 * c["value"]                 # (a reported baseline, never the target)
+    v = d["path_roofline"]["valu"]
+    assert 0 < v["frac_of_step"] < 1 and v["busy_ms_per_step"] < d["ms_per_step"]
